@@ -1,0 +1,176 @@
+"""Pins the CPU oracle (oracle/smal_oracle.py) against vectors produced by the imported reference
+(tests/golden/reference_golden.npz, generator: tests/golden/make_golden.py).  CPU only.
+
+Tolerances: the reference computes in float32, the oracle in float64, so differences are the
+reference's own round-off: 2e-5 relative on values, 2e-4 relative (norm-wise) on gradients that pass
+through the 34-step chain and 3889-vertex reductions.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import smal_oracle as so
+from smalify_amd import config as cfg
+from smalify_amd import model_io
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def test_synthetic_model_matches_generation_time_checksums(golden, synth_model):
+    md = synth_model
+    assert abs(md.v_template.astype(np.float64).sum() - golden["chk_v_template"][0]) < 1e-3
+    assert abs(np.abs(md.v_template.astype(np.float64)).sum() - golden["chk_v_template"][1]) < 1e-3
+    assert abs(md.posedirs.astype(np.float64).sum() - golden["chk_posedirs"][0]) < 1e-2
+    assert abs(np.abs(md.shapedirs.astype(np.float64)).sum() - golden["chk_shapedirs"][1]) < 1e-2
+    assert abs((md.weights.astype(np.float64) * np.arange(35)).sum() - golden["chk_weights"][0]) < 1e-2
+    assert abs((md.J_regressor.astype(np.float64) * np.arange(35)).sum() - golden["chk_jreg"][0]) < 1e-3
+    assert (md.parents == golden["parents"]).all()
+
+
+def test_known_answers_from_reference_data(golden):
+    # SURVEY §8c known-answer values (depend only on files shipped with the reference)
+    assert np.allclose(golden["init_global_rotation"], -1.20919958, atol=1e-6)
+    assert np.allclose(model_io.initial_global_rotation(), -1.20919958, atol=1e-7)
+    assert abs(golden["g4_zero_mean"] - 0.80639112) < 1e-5
+    assert abs(golden["g4_point1_mean"] - 91.9112549) < 1e-3
+    assert abs(golden["g5_zero_betas_mean"] - 5848.07471) < 0.5
+    assert np.allclose(golden["g5_init_ls"],
+                       [-0.12309442, 0.27784678, -0.6320069, -0.26995066, -0.0148344, -0.3365687], atol=1e-6)
+
+
+def test_rodrigues(golden):
+    R = so.rodrigues(torch.from_numpy(golden["g1_theta"]).double()).numpy()
+    assert np.abs(R - golden["g1_R"]).max() < 5e-6
+
+
+@pytest.mark.parametrize("scaled", [False, True])
+def test_kinematic_chain(golden, scaled):
+    theta = torch.from_numpy(golden["g2_theta"]).double()
+    Rs = so.rodrigues(theta).reshape(3, 35, 3, 3)
+    Js = torch.from_numpy(golden["g2_Js"]).double()
+    ls = torch.from_numpy(golden["g2_ls"]).double() if scaled else None
+    parents = [int(p) for p in golden["parents"]]
+    jw, a_r, a_t = so.kinematic_chain(Rs, Js, parents, ls)
+    tag = "scale" if scaled else "noscale"
+    A = golden["g2_A_" + tag]
+    assert rel(jw.numpy(), golden["g2_newJ_" + tag]) < 2e-5
+    assert rel(a_r.numpy(), A[:, :, :3, :3]) < 2e-5
+    assert rel(a_t.numpy(), A[:, :, :3, 3]) < 2e-5
+    assert (A[:, :, 3, :] == np.array([0, 0, 0, 1.0])).all()   # reference keeps the homogeneous row (0,0,0,1)
+
+
+def test_smal_forward_and_grads(golden, synth_model):
+    m = so.OracleModel(synth_model)
+    beta = torch.from_numpy(golden["g3_beta"]).double().requires_grad_(True)
+    theta = torch.from_numpy(golden["g3_theta"]).double().requires_grad_(True)
+    ls = torch.from_numpy(golden["g3_ls"]).double().requires_grad_(True)
+    verts, joints, Rs, v_shaped = so.smal_forward(m, beta, theta, ls)
+    vsel = golden["g3_vsel"]
+    assert rel(verts.detach().numpy()[:, vsel], golden["g3_verts"]) < 2e-5
+    assert rel(joints.detach().numpy(), golden["g3_joints"]) < 2e-5
+    assert rel(v_shaped.detach().numpy()[:, vsel], golden["g3_vshaped"]) < 2e-5
+    assert rel(Rs.detach().numpy(), golden["g3_Rs"]) < 2e-5
+    func = (verts[:, vsel] * torch.from_numpy(golden["g3_wv"]).double()).sum() + \
+           (joints * torch.from_numpy(golden["g3_wj"]).double()).sum()
+    func.backward()
+    assert abs(func.item() - golden["g3_func"]) < 2e-4 * abs(golden["g3_func"]) + 1e-4
+    assert rel(beta.grad.numpy(), golden["g3_dbeta"]) < 2e-4
+    assert rel(theta.grad.numpy(), golden["g3_dtheta"]) < 2e-4
+    assert rel(ls.grad.numpy(), golden["g3_dls"]) < 2e-4
+
+
+def test_smal_zero_pose_gradient(golden, synth_model):
+    """theta = 0 for every joint (state at the start of stage 1): finite values and gradients."""
+    m = so.OracleModel(synth_model)
+    theta = torch.zeros(1, 35, 3, dtype=torch.float64, requires_grad=True)
+    verts, joints, _, _ = so.smal_forward(m, torch.zeros(1, 20, dtype=torch.float64), theta)
+    (joints * torch.from_numpy(golden["g3_wj"][:1]).double()).sum().backward()
+    assert rel(joints.detach().numpy(), golden["g3z_joints"]) < 2e-5
+    assert rel(verts.detach().numpy()[:, golden["g3_vsel"]], golden["g3z_verts"]) < 2e-5
+    # float32 reference loses digits in theta/||theta+1e-8|| at 0; 1e-3 is its own noise floor here
+    assert rel(theta.grad.numpy(), golden["g3z_dtheta"]) < 1e-3
+
+
+def test_pose_prior(golden):
+    P, mu, mask = (torch.from_numpy(golden[k]).double() for k in ("pose_prec", "pose_mean", "pose_mask"))
+    x = torch.from_numpy(golden["g4_x"]).double().requires_grad_(True)
+    val = so.pose_prior_residual2(x, P, mu, mask)
+    val.mean().backward()
+    assert rel(val.detach().numpy(), golden["g4_val"]) < 2e-5
+    assert rel(x.grad.numpy(), golden["g4_dx"]) < 2e-5
+    assert np.abs(x.grad.numpy()[:, 0]).max() == 0.0     # global rotation never penalised (App. D.6)
+
+
+def _problem(golden, md, window, family1=True):
+    m = so.OracleModel(md)
+    S = int(golden["g6_image_size"])
+    N = golden["g6_target_joints"].shape[0]
+    if family1:
+        sp, sm = golden["unity_prec"], golden["unity_mean"]
+    else:
+        sp, sm = golden["fam0_prec"], golden["fam0_mean"]
+    return so.FitProblem(m, S, golden["g6_target_joints"], golden["g6_visibility"],
+                         np.zeros((N, S, S)), golden["pose_prec"], golden["pose_mean"], golden["pose_mask"],
+                         sp, sm, window, use_unity_prior=family1)
+
+
+def _params(golden, tag):
+    return {k: torch.from_numpy(golden["%s_p_%s" % (tag, k)]).double()
+            for k in ("global_rotation", "joint_rotations", "trans", "betas", "log_beta_scales")}
+
+
+CASES = [("g6_stage0_w4", 4, 0, True), ("g6_stage1_w4", 4, 1, True), ("g6_stage1_w2", 2, 1, True),
+         ("g6_stage1_w3", 3, 1, True), ("g6_family0_w4", 4, 1, False)]
+
+
+@pytest.mark.parametrize("tag,window,stage,family1", CASES)
+def test_fitter_loss_terms_and_grads(golden, synth_model, synth_model_family0, tag, window, stage, family1):
+    md = synth_model if family1 else synth_model_family0
+    p = _problem(golden, md, window, family1)
+    params = _params(golden, tag)
+    weights = golden["g6_w0"] if stage == 0 else golden["g6_w1"]
+    w_temp = float(golden["g6_wtemp"][stage])
+    vis = so.stage0_visibility(p.vis) if stage == 0 else None
+    trainable = ("global_rotation", "trans") if stage == 0 else so.PARAM_ORDER
+    total, sums, grads = so.loss_and_grads(p, params, weights, w_temp, trainable, vis)
+    assert abs(total.item() - golden[tag + "_total"]) < 3e-5 * abs(golden[tag + "_total"])
+    for k in ("joint", "pose", "splay", "betas"):
+        key = "%s_term_%s" % (tag, k)
+        if key in golden:
+            assert abs(sums[k] - golden[key]) < 3e-5 * abs(golden[key]) + 1e-6, k
+    t = golden[tag + "_temporal"]
+    assert np.allclose([sums["temp_joint"], sums["temp_global"], sums["temp_trans"]], t, rtol=3e-5, atol=1e-7)
+    for k in trainable:
+        ref = golden["%s_g_%s" % (tag, k)]
+        assert rel(grads[k].numpy(), ref) < 3e-4, (k, rel(grads[k].numpy(), ref))
+
+
+def test_adam_trajectory_matches_reference_loop(golden, synth_model):
+    """20 iterations of the reference's stage loop (6 of stage 0, 14 of stage 1, window 2, no silhouette).
+    Short horizon because the trajectory is chaotic."""
+    p = _problem(golden, synth_model, 2)
+    N = p.N
+    params = dict(
+        betas=torch.from_numpy(golden["g5_init_betas"]).double(),
+        log_beta_scales=torch.from_numpy(golden["g5_init_ls"]).double(),
+        global_rotation=torch.from_numpy(np.tile(golden["init_global_rotation"], (N, 1))).double(),
+        trans=torch.zeros(N, 3, dtype=torch.float64),
+        joint_rotations=torch.zeros(N, 34, 3, dtype=torch.float64))
+    W = np.array(cfg.OPT_WEIGHTS).T
+    hist = []
+    for stage, its in golden["g8_schedule"]:
+        weights = golden["g6_w0"] if stage == 0 else golden["g6_w1"]
+        trainable = so.trainable_names(int(stage))
+        opt = so.Adam(so.PARAM_ORDER, lr=float(W[stage][8]))
+        vis = so.stage0_visibility(p.vis) if stage == 0 else None
+        for _ in range(int(its)):
+            total, _, grads = so.loss_and_grads(p, params, weights, float(W[stage][6]), trainable, vis)
+            opt.step(params, grads)
+            hist.append(total.item())
+        for k in so.PARAM_ORDER:
+            ref = golden["g8_after_stage%d_%s" % (stage, k)]
+            assert rel(params[k].numpy(), ref) < 2e-4, (stage, k, rel(params[k].numpy(), ref))
+    assert np.allclose(hist, golden["g8_loss_history"], rtol=2e-4)
