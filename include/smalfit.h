@@ -1,0 +1,148 @@
+/* smalfit.h — C-ABI of the MI355X-native SMAL fitting engine (libsmalfit.so, built by hipcc for gfx950).
+ *
+ * The reference (benjiebob/SMALify @ /root/reference) has no FFI layer: its hot path is Python calling
+ * torch / pytorch3d.  The boundary a maintainer would bind is therefore the set of Python call sites
+ * listed in SURVEY.md §8b; every entry point below names the reference interface it replaces.
+ *
+ * Conventions
+ *   - every tensor argument is a DEVICE pointer to contiguous row-major float32 (int32 for indices)
+ *     unless the parameter is documented as "host"
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises
+ *     except smalfit_engine_status()
+ *   - functions return 0 on success, non-zero on failure; smalfit_last_error() describes the failure
+ *   - handles are thread-compatible, not thread-safe; no ownership of caller buffers is taken
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails
+ */
+#ifndef SMALFIT_H_
+#define SMALFIT_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smalfit_model smalfit_model;
+typedef struct smalfit_engine smalfit_engine;
+
+#define SMALFIT_NUM_JOINTS 35
+#define SMALFIT_NUM_MODEL_JOINTS 41
+#define SMALFIT_NUM_KEYPOINTS 25
+#define SMALFIT_NUM_LOSS_TERMS 8 /* joint, pose, splay, betas, sil_reproj, temp_joint, temp_global, temp_trans */
+
+#define SMALFIT_STATUS_BIN_OVERFLOW 1
+#define SMALFIT_STATUS_K_OVERFLOW 2
+
+int smalfit_version(void);
+const char* smalfit_last_error(void);
+
+/* ---- model constants -------------------------------------------------------------------------
+ * replaces: SMAL.__init__ tensors            reference smal_model/smal_torch.py:36-96
+ * All pointers are HOST arrays prepared by the caller (smalify_amd/model_io.py does the pickle
+ * parsing, family mean and symmetry alignment exactly as the reference). */
+typedef struct smalfit_model_desc {
+  int num_verts;            /* V (3889)                                   */
+  int num_faces;            /* F (7774)                                   */
+  int num_betas;            /* rows of shapedirs (41)                     */
+  const float* v_template;  /* (V,3)                                      */
+  const float* shapedirs;   /* (num_betas, 3V), column = 3*v + axis       */
+  const float* posedirs;    /* (306, 3V)                                  */
+  const float* J_regressor; /* (V,35) dense                               */
+  const float* weights;     /* (V,35) dense                               */
+  const int* parents;       /* (35), parents[0] = -1, parents[i] < i      */
+  const int* faces;         /* (F,3)                                      */
+} smalfit_model_desc;
+
+int smalfit_model_create(const smalfit_model_desc* desc, smalfit_model** out);
+void smalfit_model_destroy(smalfit_model* model);
+
+/* ---- engine = workspace in HBM for up to max_frames frames at image_size^2 ---------------------- */
+int smalfit_engine_create(smalfit_model* model, int max_frames, int image_size, smalfit_engine** out);
+void smalfit_engine_destroy(smalfit_engine* engine);
+/* synchronises `stream`, returns and clears the sticky status bits (SMALFIT_STATUS_*) */
+int smalfit_engine_status(smalfit_engine* engine, void* stream, int* status_bits);
+
+/* replaces: Prior.__init__ data              reference smal_fitter/priors/pose_prior_35.py:51-92
+ * host arrays: prec (105,105), mean (105), mask (105) */
+int smalfit_engine_set_pose_prior(smalfit_engine* engine, const float* prec, const float* mean,
+                                  const float* mask);
+/* replaces: betas_prec / mean_betas          reference smal_fitter/smal_fitter.py:48-69
+ * host arrays: prec (dim,dim), mean (dim); dim = 26 (unity prior: betas|log scales) or <= 20 */
+int smalfit_engine_set_shape_prior(smalfit_engine* engine, const float* prec, const float* mean, int dim);
+
+/* ---- SMAL.__call__ ------------------------------------------------------------------------------
+ * replaces: SMAL.__call__(beta, theta, betas_logscale=...)   reference smal_model/smal_torch.py:99-189
+ * beta (M,nb) theta (M,35,3) logscale (M,6) or NULL -> verts (M,V,3) joints (M,41,3)
+ * optional outputs (NULL to skip): Rs (M,35,3,3), v_shaped (M,V,3) */
+int smalfit_lbs_forward(smalfit_engine* engine, void* stream, int M, int nb, const float* beta,
+                        const float* theta, const float* logscale, float* verts, float* joints,
+                        float* Rs, float* v_shaped);
+/* adjoint of the above for upstream gradients dverts (M,V,3) and/or djoints (M,41,3) (either may be
+ * NULL): dbeta (M,nb), dtheta (M,35,3), dlogscale (M,6) or NULL.  Recomputes the forward internally. */
+int smalfit_lbs_backward(smalfit_engine* engine, void* stream, int M, int nb, const float* beta,
+                         const float* theta, const float* logscale, const float* dverts,
+                         const float* djoints, float* dbeta, float* dtheta, float* dlogscale);
+
+/* ---- batch_rodrigues ----------------------------------------------------------------------------
+ * replaces: batch_rodrigues(theta)                           reference smal_model/batch_lbs.py:33-52 */
+int smalfit_rodrigues(void* stream, int count, const float* theta, float* R);
+int smalfit_rodrigues_backward(void* stream, int count, const float* theta, const float* dR, float* dtheta);
+
+/* ---- Renderer.forward ---------------------------------------------------------------------------
+ * replaces: Renderer.forward(vertices, points, faces)        reference smal_fitter/p3d_renderer.py:61-74
+ * verts (M,V,3) world space -> sil (M,S,S) soft silhouette (sigma 1e-4, blur log(9999)*1e-4, K=100)
+ * points (M,P,3) -> proj_points (M,P,2) as (row, col) screen coordinates; points may be NULL */
+int smalfit_render_forward(smalfit_engine* engine, void* stream, int M, const float* verts,
+                           const float* points, int P, float* sil, float* proj_points);
+/* adjoint wrt verts given the saved silhouette and dL/dsil (M,S,S) */
+int smalfit_render_backward(smalfit_engine* engine, void* stream, int M, const float* verts,
+                            const float* sil, const float* dsil, float* dverts);
+int smalfit_project_points_backward(void* stream, int count, int image_size, const float* points,
+                                    const float* dproj, float* dpoints);
+
+/* ---- SMALFitter.forward + get_temporal + backward, fused ------------------------------------------
+ * replaces: SMALFitter.forward / get_temporal and the autograd backward of their sum
+ *           reference smal_fitter/smal_fitter.py:107-190, smal_fitter/optimize_to_joints.py:117-136
+ * Evaluates M consecutive frames, grouped into windows of `window` frames (the last may be ragged),
+ * with the reference's per-window normalisers, and writes every loss term plus the gradient of
+ * their sum with respect to each parameter tensor. */
+typedef struct smalfit_fit_args {
+  int num_frames;                 /* M                                                          */
+  int window;                     /* WINDOW_SIZE; normalisers use the size of each frame's window */
+  int logscale_mode;              /* 0: no limb scales, 1: shared (6,), 2: per frame (M,6)       */
+  int temporal;                   /* include the temporal term over these M frames              */
+  int shape_prior_dim;            /* 0 = use the dim given to set_shape_prior                    */
+  float w_j2d, w_sil, w_betas, w_pose, w_splay, w_temp;
+  const float* betas;             /* (20,) shared                                               */
+  const float* log_beta_scales;   /* (6,) or (M,6) or NULL                                      */
+  const float* global_rotation;   /* (M,3)                                                      */
+  const float* joint_rotations;   /* (M,34,3)                                                   */
+  const float* trans;             /* (M,3)                                                      */
+  const float* global_mask;       /* (3,)   or NULL (= ones)                                    */
+  const float* rotation_mask;     /* (34,3) or NULL (= ones)                                    */
+  const float* target_joints;     /* (M,25,2) (row, col)                                        */
+  const float* target_visibility; /* (M,25) float {0,1}                                         */
+  const float* target_sil;        /* (M,S,S); may be NULL when w_sil == 0                       */
+  const float* halo_prev;         /* (108,) masked theta(105)|trans(3) of the frame before frame 0, or NULL */
+  const float* halo_next;         /* (108,) of the frame after frame M-1, or NULL               */
+  float* losses;                  /* (8,) see SMALFIT_NUM_LOSS_TERMS                            */
+  float* g_betas;                 /* (20,)           or NULL                                    */
+  float* g_log_beta_scales;       /* (6,) / (M,6)    or NULL                                    */
+  float* g_global_rotation;       /* (M,3)           or NULL                                    */
+  float* g_joint_rotations;       /* (M,34,3)        or NULL                                    */
+  float* g_trans;                 /* (M,3)           or NULL                                    */
+  float* sil_out;                 /* (M,S,S) rendered silhouettes or NULL                       */
+  float* proj_out;                /* (M,25,2) projected keypoints or NULL                       */
+  float* verts_out;               /* (M,V,3) translated vertices or NULL                        */
+} smalfit_fit_args;
+
+int smalfit_fit_eval(smalfit_engine* engine, void* stream, const smalfit_fit_args* args);
+
+/* ---- torch.optim.Adam.step -----------------------------------------------------------------------
+ * replaces: torch.optim.Adam(lr, betas=(0.5, 0.999)).step()  reference smal_fitter/optimize_to_joints.py:96,137
+ * t = 1-based step count; eps outside the bias-corrected sqrt, as torch does */
+int smalfit_adam_step(void* stream, int count, float* param, const float* grad, float* exp_avg,
+                      float* exp_avg_sq, float lr, float beta1, float beta2, float eps, int t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMALFIT_H_ */

@@ -1,0 +1,118 @@
+"""ctypes binding of libsmalfit.so (C-ABI declared in include/smalfit.h).
+
+The library is built in-tree by `build_library()` (hipcc --offload-arch=gfx950) and loaded from
+`smalify_amd/libsmalfit.so`.  There is no fallback: if the shared object is missing or cannot be
+loaded, `load()` raises and every product entry point fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsmalfit.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_lib = None
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int)
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("num_verts", C.c_int), ("num_faces", C.c_int), ("num_betas", C.c_int),
+                ("v_template", C.c_void_p), ("shapedirs", C.c_void_p), ("posedirs", C.c_void_p),
+                ("J_regressor", C.c_void_p), ("weights", C.c_void_p), ("parents", C.c_void_p),
+                ("faces", C.c_void_p)]
+
+
+class FitArgs(C.Structure):
+    _fields_ = [("num_frames", C.c_int), ("window", C.c_int), ("logscale_mode", C.c_int),
+                ("temporal", C.c_int), ("shape_prior_dim", C.c_int),
+                ("w_j2d", C.c_float), ("w_sil", C.c_float), ("w_betas", C.c_float),
+                ("w_pose", C.c_float), ("w_splay", C.c_float), ("w_temp", C.c_float),
+                ("betas", C.c_void_p), ("log_beta_scales", C.c_void_p), ("global_rotation", C.c_void_p),
+                ("joint_rotations", C.c_void_p), ("trans", C.c_void_p), ("global_mask", C.c_void_p),
+                ("rotation_mask", C.c_void_p), ("target_joints", C.c_void_p),
+                ("target_visibility", C.c_void_p), ("target_sil", C.c_void_p),
+                ("halo_prev", C.c_void_p), ("halo_next", C.c_void_p), ("losses", C.c_void_p),
+                ("g_betas", C.c_void_p), ("g_log_beta_scales", C.c_void_p),
+                ("g_global_rotation", C.c_void_p), ("g_joint_rotations", C.c_void_p),
+                ("g_trans", C.c_void_p), ("sil_out", C.c_void_p), ("proj_out", C.c_void_p),
+                ("verts_out", C.c_void_p)]
+
+
+# every symbol include/smalfit.h declares: (restype, argtypes)
+_VP, _I, _F = C.c_void_p, C.c_int, C.c_float
+SIGNATURES = {
+    "smalfit_version": (_I, []),
+    "smalfit_last_error": (C.c_char_p, []),
+    "smalfit_model_create": (_I, [C.POINTER(ModelDesc), C.POINTER(_VP)]),
+    "smalfit_model_destroy": (None, [_VP]),
+    "smalfit_engine_create": (_I, [_VP, _I, _I, C.POINTER(_VP)]),
+    "smalfit_engine_destroy": (None, [_VP]),
+    "smalfit_engine_status": (_I, [_VP, _VP, c_int_p]),
+    "smalfit_engine_set_pose_prior": (_I, [_VP, _VP, _VP, _VP]),
+    "smalfit_engine_set_shape_prior": (_I, [_VP, _VP, _VP, _I]),
+    "smalfit_lbs_forward": (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "smalfit_lbs_backward": (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "smalfit_rodrigues": (_I, [_VP, _I, _VP, _VP]),
+    "smalfit_rodrigues_backward": (_I, [_VP, _I, _VP, _VP, _VP]),
+    "smalfit_render_forward": (_I, [_VP, _VP, _I, _VP, _VP, _I, _VP, _VP]),
+    "smalfit_render_backward": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP]),
+    "smalfit_project_points_backward": (_I, [_VP, _I, _I, _VP, _VP, _VP]),
+    "smalfit_fit_eval": (_I, [_VP, _VP, C.POINTER(FitArgs)]),
+    "smalfit_adam_step": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _F, _F, _F, _F, _I]),
+}
+
+
+class SmalfitError(RuntimeError):
+    pass
+
+
+def build_library(verbose=False):
+    """Compile smalify_amd/csrc for gfx950 into smalify_amd/libsmalfit.so (cross-compiles without a GPU)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           os.path.join(CSRC, "smalfit_kernels.hip"), "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def needs_rebuild():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    srcs.append(os.path.join(_HERE, "..", "include", "smalfit.h"))
+    return any(os.path.getmtime(s) > t for s in srcs if os.path.exists(s))
+
+
+def load():
+    """Load libsmalfit.so and attach signatures. Raises SmalfitError if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SmalfitError(
+            "libsmalfit.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "— smalify_amd has no CPU fallback." % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as exc:
+        raise SmalfitError("cannot load %s: %s" % (LIB_PATH, exc)) from exc
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().smalfit_last_error()
+        raise SmalfitError("%s failed: %s" % (what or "smalfit call", msg.decode() if msg else "unknown error"))

@@ -1,0 +1,87 @@
+// Internal declarations shared by the kernels and the host-side engine. Not part of the C-ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "smalfit_math.h"
+
+#define SMALFIT_STATUS_BIN_OVERFLOW 1   // tile lists exceeded the per-frame capacity
+#define SMALFIT_STATUS_K_OVERFLOW 2     // a pixel had more than 100 contributing faces (K cap not applied)
+
+namespace smalfit {
+
+// device-resident model constants (pointers into one allocation owned by smalfit_model)
+struct ModelDev {
+  int V, Vp, F, NBall;
+  const float* vt;        // [3][Vp]
+  const float* sd;        // [NBall][3][Vp]
+  const float* pd;        // [306][3][Vp]
+  int Kw;                 // skin weights, ELL by vertex
+  const int* w_j;         // [Kw][Vp]
+  const float* w_val;     // [Kw][Vp]
+  const int* wc_off;      // skin weights, CSC by joint [36]
+  const int* wc_v;
+  const float* wc_val;
+  const int* jr_off;      // joint regressor, CSC by joint [36]
+  const int* jr_v;
+  const float* jr_val;
+  int Kj;                 // joint regressor, ELL by vertex
+  const int* jrv_j;       // [Kj][Vp]
+  const float* jrv_val;   // [Kj][Vp]
+  const float* Jt;        // [105]  rest joints at beta = 0
+  const float* JS;        // [105][NBall]  d(rest joints)/d(beta)
+  const int* parents;     // [35]
+  const int* faces;       // [F][3]
+  const int* vf_off;      // [V+1] vertex -> incident (face*3+corner)
+  const int* vf_idx;
+  const int* scale_idx;   // [105] log-scale index per (joint, axis) or -1
+  int landmarks[6];
+};
+
+struct LossArgs {
+  int M, S, window;
+  const float* theta;      // [M][105] masked
+  const float* trans;      // [M][3]
+  const float* joints;     // [M][41][3] (untranslated)
+  const int* canon;        // [25]
+  const float* tj;         // [M][25][2] (row, col)
+  const float* vis;        // [M][25]
+  float w_j2d, w_pose, w_splay, w_temp;
+  const float* pose_prec;  // [105][105]
+  const float* pose_mean;  // [105]
+  const float* pose_mask;  // [105]
+  const float* halo_prev;  // [108] neighbour frame before frame 0 (theta 105 | trans 3) or null
+  const float* halo_next;  // [108] neighbour frame after frame M-1 or null
+  float* proj_out;         // [M][25][2] or null
+  float* dth_direct;       // [M][105]
+  float* dJ41;             // [M][41][3]
+  float* dtr_direct;       // [M][3]
+  float* loss_part;        // [M][8]
+};
+
+struct AssembleArgs {
+  int M, S, T, window, nb, NBall, nblk_beta, nvt;
+  int betas_shared, ls_shared;
+  float w_sil;
+  const float* dbeta_part;
+  const float* dJrest;
+  const float* JS;
+  const float* gb_prior;
+  const float* gls_prior;
+  const float* dls;
+  const float* dtheta;
+  const float* gmask;
+  const float* rmask;
+  const float* dtr_direct;
+  const float* dtr_part;
+  const float* loss_part;
+  const float* loss_betas;
+  const float* tile_loss;
+  float* g_betas;
+  float* g_ls;
+  float* g_grot;
+  float* g_jrot;
+  float* g_trans;
+  float* losses;
+};
+
+}  // namespace smalfit

@@ -1,0 +1,1285 @@
+// HIP kernels of the SMAL fitting engine for gfx950 (MI355X / CDNA4).
+//
+// Data layout in HBM (all float32 unless noted):
+//   model bases are *planar*:  vt[3][Vp], sd[nb][3][Vp], pd[306][3][Vp]  (Vp = V rounded up to 256,
+//   zero padded) so that a wavefront of 64 consecutive vertices issues fully coalesced 256-byte loads;
+//   per-frame vertex buffers are planar too: x[n][3][Vp].
+//   skin weights / joint regressor are stored sparse (ELL by vertex, CSC by joint) — the dense (V,35)
+//   matrices of the reference (smal_torch.py:78-96) are mostly zeros; a dense matrix is simply an ELL
+//   with 35 entries per row, the code path is the same and the sums run in the same joint order.
+//
+// Kernel -> reference map (file:line into /root/reference):
+//   shape_kernel        smal_torch.py:115 (+ :125-128 through the precomputed J0 + JS beta)
+//   pose_kernel         batch_lbs.py:33-52 (Rodrigues), :105-129 (limb scales), :131-168 (chain, A)
+//   skin_kernel         smal_torch.py:138-163 (pose blend, W*A, skinning) + renderer camera transform
+//   joints_kernel       smal_torch.py:171-184
+//   loss_kernel         smal_fitter.py:129-132,140-160,177-190 ; pose_prior_35.py:117-124
+//   shape_prior_kernel  smal_fitter.py:162-171
+//   face_bbox/bin/raster_fwd/raster_bwd   p3d_renderer.py:26-39,65-66 (pytorch3d rasterize + blend)
+//   vertex_bwd .. chain_bwd               autograd of the above (optimize_to_joints.py:136)
+//   adam_kernel         optimize_to_joints.py:96,137 (torch.optim.Adam, betas=(0.5,0.999))
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "smalfit_internal.h"
+
+namespace smalfit {
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum of `v` (blockDim.x multiple of 64, <= 1024); result valid in every thread
+__device__ __forceinline__ float block_sum(float v, float* red /* >= 16 floats of LDS */) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+__device__ __forceinline__ int frame_window_size(int n, int M, int window) {
+  // frames are grouped into consecutive windows of `window` frames, the last one may be ragged
+  // (optimize_to_joints.py:119-120)
+  const int start = (n / window) * window;
+  const int rem = M - start;
+  return rem < window ? rem : window;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: shape blend + rest joints
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+shape_kernel(ModelDev m, const float* __restrict__ betas, int betas_stride, int nb,
+             float* __restrict__ v_shaped /*[nbs][3][Vp]*/, float* __restrict__ Jrest /*[nbs][105]*/) {
+  const int s = blockIdx.y;
+  const float* beta = betas + (size_t)s * betas_stride;
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  const int Vp = m.Vp;
+  if (v < Vp) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float acc = m.vt[a * Vp + v];
+      for (int b = 0; b < nb; ++b) acc = fmaf(beta[b], m.sd[((size_t)b * 3 + a) * Vp + v], acc);
+      v_shaped[((size_t)s * 3 + a) * Vp + v] = acc;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 105) {
+    float acc = m.Jt[threadIdx.x];
+    for (int b = 0; b < nb; ++b) acc = fmaf(m.JS[threadIdx.x * m.NBall + b], beta[b], acc);
+    Jrest[s * 105 + threadIdx.x] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: per-frame pose: Rodrigues, limb scales, kinematic chain, skinning transforms, pose feature
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+pose_kernel(ModelDev m, int M, int Mp,
+            const float* __restrict__ theta /*[M][35][3] already masked*/,
+            const float* __restrict__ logscale, int ls_stride,
+            const float* __restrict__ Jrest, int j_stride,
+            float* __restrict__ Rm /*[M][35][9]*/, float* __restrict__ Gm /*[M][35][12]*/,
+            float* __restrict__ scm /*[M][35][3]*/, float* __restrict__ Am /*[M][35][12]*/,
+            float* __restrict__ pfT /*[308][Mp]*/) {
+  __shared__ float R[35][9];
+  __shared__ float sc[35][3];
+  __shared__ float G[35][12];
+  __shared__ float J[35][3];
+  __shared__ int par[35];
+  const int n = blockIdx.x, l = threadIdx.x;
+  if (l < 35) {
+    float th[3] = {theta[(n * 35 + l) * 3], theta[(n * 35 + l) * 3 + 1], theta[(n * 35 + l) * 3 + 2]};
+    float r[9];
+    rodrigues_fwd(th, r);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { R[l][e] = r[e]; Rm[(n * 35 + l) * 9 + e] = r[e]; }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int idx = m.scale_idx[l * 3 + a];
+      const float sv = (logscale != nullptr && idx >= 0) ? expf(logscale[(size_t)n * ls_stride + idx]) : 1.0f;
+      sc[l][a] = sv;
+      scm[(n * 35 + l) * 3 + a] = sv;
+      J[l][a] = Jrest[(size_t)n * j_stride + l * 3 + a];
+    }
+    par[l] = m.parents[l];
+  }
+  __syncthreads();
+  for (int idx = l; idx < 306; idx += 64) {
+    const int j = idx / 9 + 1, e = idx % 9;
+    pfT[(size_t)idx * Mp + n] = R[j][e] - ((e & 3) == 0 ? 1.0f : 0.0f);
+  }
+  if (l < 12) {
+    const int a = l >> 2, b = l & 3;
+    G[0][l] = (b < 3) ? R[0][a * 3 + b] : J[0][a];
+  }
+  __syncthreads();
+  for (int i = 1; i < 35; ++i) {
+    const int p = par[i];
+    if (l < 12) {
+      const int a = l >> 2, b = l & 3;
+      float acc;
+      if (b < 3) {
+        acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc = fmaf(G[p][a * 4 + c], R[i][c * 3 + b] * sc[i][b] / sc[p][c], acc);
+      } else {
+        acc = G[p][a * 4 + 3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc = fmaf(G[p][a * 4 + c], J[i][c] - J[p][c], acc);
+      }
+      G[i][l] = acc;
+    }
+    __syncthreads();
+  }
+  for (int idx = l; idx < 35 * 12; idx += 64) {
+    const int j = idx / 12, e = idx % 12, a = e >> 2, b = e & 3;
+    float val = G[j][e];
+    if (b == 3) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) val = fmaf(-G[j][a * 4 + c], J[j][c], val);
+    }
+    Am[(size_t)n * 420 + idx] = val;
+    Gm[(size_t)n * 420 + idx] = G[j][e];
+  }
+}
+
+// theta[n][0] = global_rotation[n] * gmask ; theta[n][1+j] = joint_rotations[n][j] * rmask[j]
+__global__ void build_theta_kernel(int M, const float* __restrict__ grot, const float* __restrict__ jrot,
+                                   const float* __restrict__ gmask, const float* __restrict__ rmask,
+                                   float* __restrict__ theta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * 105) return;
+  const int n = i / 105, e = i % 105;
+  theta[i] = (e < 3) ? grot[n * 3 + e] * gmask[e] : jrot[n * 102 + (e - 3)] * rmask[e - 3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: pose blend + skinning + camera transform.  block = 64 vertices x FR frames, 4 waves split K=306
+// ------------------------------------------------------------------------------------------------
+template <int FR>
+__global__ void __launch_bounds__(256)
+skin_kernel(ModelDev m, int M, int Mp, const float* __restrict__ v_shaped, int vs_stride /*0 | 3*Vp*/,
+            const float* __restrict__ pfT, const float* __restrict__ Am, const float* __restrict__ trans,
+            float* __restrict__ vposed, float* __restrict__ verts, float* __restrict__ proj) {
+  __shared__ float red[4][FR * 3][64];
+  __shared__ float As[FR][420];
+  const int Vp = m.Vp;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int v = blockIdx.x * 64 + lane;
+  const int n0 = blockIdx.y * FR;
+  for (int i = threadIdx.x; i < FR * 420; i += 256) {
+    const int f = i / 420;
+    As[f][i % 420] = (n0 + f < M) ? Am[(size_t)(n0 + f) * 420 + (i % 420)] : 0.f;
+  }
+  float acc[FR][3];
+#pragma unroll
+  for (int f = 0; f < FR; ++f) acc[f][0] = acc[f][1] = acc[f][2] = 0.f;
+  const int k0 = (w * 306) / 4, k1 = ((w + 1) * 306) / 4;
+  for (int k = k0; k < k1; ++k) {
+    const float p0 = m.pd[((size_t)k * 3 + 0) * Vp + v];
+    const float p1 = m.pd[((size_t)k * 3 + 1) * Vp + v];
+    const float p2 = m.pd[((size_t)k * 3 + 2) * Vp + v];
+    const float* pf = pfT + (size_t)k * Mp + n0;     // wave-uniform -> scalar loads
+#pragma unroll
+    for (int f = 0; f < FR; ++f) {
+      const float c = pf[f];
+      acc[f][0] = fmaf(c, p0, acc[f][0]);
+      acc[f][1] = fmaf(c, p1, acc[f][1]);
+      acc[f][2] = fmaf(c, p2, acc[f][2]);
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < FR; ++f) {
+    red[w][f * 3 + 0][lane] = acc[f][0];
+    red[w][f * 3 + 1][lane] = acc[f][1];
+    red[w][f * 3 + 2][lane] = acc[f][2];
+  }
+  __syncthreads();
+  // phase 2: wave w finishes frames f = w, w+4, ...
+  for (int f = w; f < FR; f += 4) {
+    const int n = n0 + f;
+    if (n >= M) break;
+    const float* vs = v_shaped + (size_t)n * vs_stride;
+    float vp[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      vp[a] = vs[a * Vp + v] + ((red[0][f * 3 + a][lane] + red[1][f * 3 + a][lane]) +
+                                (red[2][f * 3 + a][lane] + red[3][f * 3 + a][lane]));
+      vposed[((size_t)n * 3 + a) * Vp + v] = vp[a];
+    }
+    float T[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) T[e] = 0.f;
+    for (int e = 0; e < m.Kw; ++e) {
+      const int j = m.w_j[e * Vp + v];
+      const float wv = m.w_val[e * Vp + v];
+      const float* A = &As[f][j * 12];
+#pragma unroll
+      for (int c = 0; c < 12; ++c) T[c] = fmaf(wv, A[c], T[c]);
+    }
+    float o[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      o[a] = fmaf(T[a * 4], vp[0], fmaf(T[a * 4 + 1], vp[1], fmaf(T[a * 4 + 2], vp[2], T[a * 4 + 3])));
+      verts[((size_t)n * 3 + a) * Vp + v] = o[a];
+    }
+    float xn, yn, zv;
+    world_to_ndc(o[0] + trans[n * 3], o[1] + trans[n * 3 + 1], o[2] + trans[n * 3 + 2], xn, yn, zv);
+    proj[((size_t)n * 3 + 0) * Vp + v] = xn;
+    proj[((size_t)n * 3 + 1) * Vp + v] = yn;
+    proj[((size_t)n * 3 + 2) * Vp + v] = zv;
+  }
+}
+
+// camera transform only (Renderer called with externally supplied vertices): vin (M,V,3) interleaved
+__global__ void project_verts_kernel(int M, int V, int Vp, const float* __restrict__ vin,
+                                     float* __restrict__ proj) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (v >= Vp) return;
+  float xn = 0.f, yn = 0.f, zv = 1.f;
+  if (v < V) {
+    const float* p = vin + ((size_t)n * V + v) * 3;
+    world_to_ndc(p[0], p[1], p[2], xn, yn, zv);
+  }
+  proj[((size_t)n * 3 + 0) * Vp + v] = xn;
+  proj[((size_t)n * 3 + 1) * Vp + v] = yn;
+  proj[((size_t)n * 3 + 2) * Vp + v] = zv;
+}
+
+// planar [n][3][Vp] -> interleaved (M,V,3), optionally + per-frame offset
+__global__ void planar_to_interleaved_kernel(int M, int V, int Vp, const float* __restrict__ src, int src_stride,
+                                             const float* __restrict__ offs, float* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (i >= V * 3) return;
+  const int v = i / 3, a = i % 3;
+  float val = src[(size_t)n * src_stride + a * Vp + v];
+  if (offs) val += offs[n * 3 + a];
+  dst[(size_t)n * V * 3 + i] = val;
+}
+
+__global__ void interleaved_to_planar_kernel(int M, int V, int Vp, const float* __restrict__ src,
+                                             float* __restrict__ dst) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (v >= Vp) return;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    dst[((size_t)n * 3 + a) * Vp + v] = (v < V) ? src[((size_t)n * V + v) * 3 + a] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: posed joints (35 regressed through the sparse regressor + 6 landmark vertices)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128)
+joints_kernel(ModelDev m, const float* __restrict__ verts, float* __restrict__ joints /*[M][41][3]*/) {
+  __shared__ float red[16];
+  const int j = blockIdx.x, n = blockIdx.y, Vp = m.Vp;
+  const float* vx = verts + (size_t)n * 3 * Vp;
+  if (j >= 35) {
+    if (threadIdx.x < 3) joints[((size_t)n * 41 + j) * 3 + threadIdx.x] = vx[threadIdx.x * Vp + m.landmarks[j - 35]];
+    return;
+  }
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int i = m.jr_off[j] + threadIdx.x; i < m.jr_off[j + 1]; i += 128) {
+    const int v = m.jr_v[i];
+    const float c = m.jr_val[i];
+    a0 = fmaf(c, vx[v], a0);
+    a1 = fmaf(c, vx[Vp + v], a1);
+    a2 = fmaf(c, vx[2 * Vp + v], a2);
+  }
+  a0 = block_sum(a0, red);
+  a1 = block_sum(a1, red);
+  a2 = block_sum(a2, red);
+  if (threadIdx.x == 0) {
+    float* o = joints + ((size_t)n * 41 + j) * 3;
+    o[0] = a0; o[1] = a1; o[2] = a2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: per-frame losses with their direct adjoints: keypoints, pose prior, splay, temporal
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128)
+loss_kernel(LossArgs a) {
+  __shared__ float th[105], x[105], res[105], dth[105];
+  __shared__ float dJ[41 * 3];
+  __shared__ float red[16];
+  const int n = blockIdx.x, t = threadIdx.x;
+  const int Bn = frame_window_size(n, a.M, a.window);
+  for (int i = t; i < 105; i += 128) { th[i] = a.theta[n * 105 + i]; dth[i] = 0.f; }
+  for (int i = t; i < 123; i += 128) dJ[i] = 0.f;
+  __syncthreads();
+  const float tx = a.trans[n * 3], ty = a.trans[n * 3 + 1], tz = a.trans[n * 3 + 2];
+  float l_joint = 0.f, l_pose = 0.f, l_splay = 0.f, l_tj = 0.f, l_tg = 0.f, l_tt = 0.f;
+  // ---- keypoints (smal_fitter.py:129-144, p3d_renderer.py:67-68) --------------------------------
+  if (t < 25) {
+    const int cj = a.canon[t];
+    const float* jp = a.joints + ((size_t)n * 41 + cj) * 3;
+    float xn, yn, zv;
+    world_to_ndc(jp[0] + tx, jp[1] + ty, jp[2] + tz, xn, yn, zv);
+    const float half = 0.5f * (float)(a.S - 1);
+    const float row = half * (1.0f - yn), col = half * (1.0f - xn);
+    if (a.proj_out) { a.proj_out[(n * 25 + t) * 2] = row; a.proj_out[(n * 25 + t) * 2 + 1] = col; }
+    if (a.w_j2d > 0.f && a.vis[n * 25 + t] != 0.f) {
+      const float dr = row - a.tj[(n * 25 + t) * 2], dc = col - a.tj[(n * 25 + t) * 2 + 1];
+      l_joint = dr * dr + dc * dc;
+      const float k = 2.0f * a.w_j2d / (50.0f * (float)Bn);
+      // row = half (1 - yn), col = half (1 - xn)
+      float gx, gy, gz;
+      world_to_ndc_bwd(xn, yn, zv, -half * k * dc, -half * k * dr, gx, gy, gz);
+      atomicAdd(&dJ[cj * 3 + 0], gx);
+      atomicAdd(&dJ[cj * 3 + 1], gy);
+      atomicAdd(&dJ[cj * 3 + 2], gz);
+    }
+  }
+  // ---- pose prior (pose_prior_35.py:117-124) ------------------------------------------------------
+  if (a.w_pose > 0.f) {
+    if (t < 105) x[t] = th[t] - a.pose_mean[t];
+    __syncthreads();
+    if (t < 105) {
+      float acc = 0.f;
+      for (int r = 0; r < 105; ++r) acc = fmaf(x[r], a.pose_prec[r * 105 + t], acc);
+      acc *= a.pose_mask[t];
+      res[t] = acc * a.pose_mask[t];        // d(res^2)/d(pre-mask) = 2 res mask
+      l_pose = acc * acc;
+    }
+    __syncthreads();
+    if (t < 105) {
+      float acc = 0.f;
+      for (int c = 0; c < 105; ++c) acc = fmaf(res[c], a.pose_prec[t * 105 + c], acc);
+      dth[t] += acc * (2.0f * a.w_pose / (105.0f * (float)Bn));
+    }
+  }
+  // ---- splay (smal_fitter.py:159-160) --------------------------------------------------------------
+  if (a.w_splay > 0.f && t >= 3 && t < 105 && ((t % 3) != 1)) {
+    l_splay = th[t] * th[t];
+    dth[t] += 2.0f * a.w_splay * th[t];
+  }
+  // ---- temporal smoothness (smal_fitter.py:177-190); pair (i, i+1) is owned by frame i ------------
+  float dtr = 0.f;
+  if (a.w_temp > 0.f && t < 108) {
+    const bool is_tr = t >= 105;
+    const int e = is_tr ? t - 105 : t;
+    const float D = is_tr ? 3.0f : (e < 3 ? 3.0f : 102.0f);
+    const float cur = is_tr ? a.trans[n * 3 + e] : th[e];
+    float g = 0.f;
+    // next neighbour (owned pair)
+    bool has_next = (n + 1 < a.M) || (a.halo_next != nullptr);
+    if (has_next) {
+      const float nxt = (n + 1 < a.M) ? (is_tr ? a.trans[(n + 1) * 3 + e] : a.theta[(n + 1) * 105 + e])
+                                      : a.halo_next[is_tr ? 105 + e : e];
+      const float d = cur - nxt;
+      const float term = d * d * (a.w_temp / D);
+      if (is_tr) l_tt = term; else if (e < 3) l_tg = term; else l_tj = term;
+      g += d;
+    }
+    bool has_prev = (n > 0) || (a.halo_prev != nullptr);
+    if (has_prev) {
+      const float prv = (n > 0) ? (is_tr ? a.trans[(n - 1) * 3 + e] : a.theta[(n - 1) * 105 + e])
+                                : a.halo_prev[is_tr ? 105 + e : e];
+      g += cur - prv;
+    }
+    g *= 2.0f * a.w_temp / D;
+    if (is_tr) dtr = g; else dth[e] += g;
+  }
+  __syncthreads();
+  // ---- outputs ---------------------------------------------------------------------------------------
+  for (int i = t; i < 105; i += 128) a.dth_direct[n * 105 + i] = dth[i];
+  for (int i = t; i < 123; i += 128) a.dJ41[n * 123 + i] = dJ[i];
+  if (t >= 105 && t < 108) {
+    // d trans: temporal part + sum over the 41 joint adjoints (joints = regress(verts) + trans)
+    float s = dtr;
+    const int e = t - 105;
+    for (int j = 0; j < 41; ++j) s += dJ[j * 3 + e];
+    a.dtr_direct[n * 3 + e] = s;
+  }
+  const float nj = 1.0f / (50.0f * (float)Bn), np_ = 1.0f / (105.0f * (float)Bn);
+  l_joint = block_sum(l_joint, red);
+  l_pose = block_sum(l_pose, red);
+  l_splay = block_sum(l_splay, red);
+  l_tj = block_sum(l_tj, red);
+  l_tg = block_sum(l_tg, red);
+  l_tt = block_sum(l_tt, red);
+  if (t == 0) {
+    float* o = a.loss_part + n * 8;
+    o[0] = a.w_j2d * nj * l_joint;
+    o[1] = a.w_pose * np_ * l_pose;
+    o[2] = a.w_splay * l_splay;
+    o[3] = 0.f;                // betas (shape_prior_kernel)
+    o[4] = 0.f;                // silhouette (tile partials)
+    o[5] = l_tj; o[6] = l_tg; o[7] = l_tt;
+  }
+}
+
+// shape prior (smal_fitter.py:162-171): loss = w * mean(((b|ls) - mu) P)^2 counted once per window.
+// single block; betas/logscale shared across frames (fitter) -> grads are for the shared vectors.
+__global__ void __launch_bounds__(64)
+shape_prior_kernel(const float* __restrict__ betas, const float* __restrict__ logscale, int use_ls,
+                   const float* __restrict__ prec, const float* __restrict__ mean, int D,
+                   float w_eff /* w_betas * num_windows */, float* __restrict__ loss_out,
+                   float* __restrict__ gb /*[20]*/, float* __restrict__ gls /*[6]*/) {
+  __shared__ float x[32], res[32];
+  const int t = threadIdx.x;
+  if (t < D) x[t] = ((t < 20) ? betas[t] : logscale[t - 20]) - mean[t];
+  __syncthreads();
+  float l = 0.f;
+  if (t < D) {
+    float acc = 0.f;
+    for (int r = 0; r < D; ++r) acc = fmaf(x[r], prec[r * D + t], acc);
+    res[t] = acc;
+    l = acc * acc;
+  }
+  __syncthreads();
+  l = wave_sum(l);
+  if (t == 0) *loss_out = w_eff * l / (float)D;
+  if (t < D) {
+    float acc = 0.f;
+    for (int c = 0; c < D; ++c) acc = fmaf(res[c], prec[t * D + c], acc);
+    acc *= 2.0f * w_eff / (float)D;
+    if (t < 20) gb[t] = acc; else if (use_ls) gls[t - 20] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: soft-silhouette rasteriser
+//
+// pytorch3d keeps, per pixel, only the faces_per_pixel = 100 candidates nearest in depth.  With the
+// reference's head-on initial pose a pixel sees hundreds of candidates, so the truncation is
+// first-class here:  faces are depth-sorted once per frame (sort_faces_kernel), tile lists inherit that
+// order (bin_kernel is a stable compaction), and raster_fwd_kernel keeps a per-pixel sorted array of the
+// K smallest depths in LDS.  Its K-th entry is the pixel's depth threshold zthr, stored next to the
+// adjoint seed so that raster_bwd_kernel applies exactly the same truncation.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned orderable(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// 5a: per-face validity, conservative pixel box of the blur-expanded triangle, depth lower bound
+__global__ void __launch_bounds__(256)
+face_bbox_kernel(ModelDev m, int S, const float* __restrict__ proj, int2* __restrict__ fbox,
+                 float* __restrict__ fzlow, unsigned long long* __restrict__ fkey) {
+  const int f = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (f >= m.F) return;
+  const int Vp = m.Vp;
+  const float* px = proj + (size_t)n * 3 * Vp;
+  const int i0 = m.faces[f * 3], i1 = m.faces[f * 3 + 1], i2 = m.faces[f * 3 + 2];
+  FaceRec r;
+  const bool ok = make_face_rec(px[i0], px[Vp + i0], px[2 * Vp + i0], px[i1], px[Vp + i1], px[2 * Vp + i1],
+                                px[i2], px[Vp + i2], px[2 * Vp + i2], r);
+  int2 box = make_int2(1, 1);     // c0=1 > c1=0 : empty
+  float zlow = __int_as_float(0x7f800000);
+  if (ok) {
+    const float xlo = fminf(px[i0], fminf(px[i1], px[i2])) - kBlurSqrt;
+    const float xhi = fmaxf(px[i0], fmaxf(px[i1], px[i2])) + kBlurSqrt;
+    const float ylo = fminf(px[Vp + i0], fminf(px[Vp + i1], px[Vp + i2])) - kBlurSqrt;
+    const float yhi = fmaxf(px[Vp + i0], fmaxf(px[Vp + i1], px[Vp + i2])) + kBlurSqrt;
+    // pixel centre x_p = 1 - (2c+1)/S  =>  c = ((1 - x_p) S - 1) / 2 ; one pixel of slack either side
+    const float fs = (float)S;
+    float c0 = floorf(((1.0f - xhi) * fs - 1.0f) * 0.5f) - 1.0f;
+    float c1 = ceilf(((1.0f - xlo) * fs - 1.0f) * 0.5f) + 1.0f;
+    float r0 = floorf(((1.0f - yhi) * fs - 1.0f) * 0.5f) - 1.0f;
+    float r1 = ceilf(((1.0f - ylo) * fs - 1.0f) * 0.5f) + 1.0f;
+    c0 = fminf(fmaxf(c0, 0.f), fs - 1.f); c1 = fminf(fmaxf(c1, -1.f), fs - 1.f);
+    r0 = fminf(fmaxf(r0, 0.f), fs - 1.f); r1 = fminf(fmaxf(r1, -1.f), fs - 1.f);
+    const bool finite = (xlo == xlo) && (xhi == xhi) && (ylo == ylo) && (yhi == yhi);
+    const bool onscreen = finite && (xhi >= -1.0f) && (xlo <= 1.0f) && (yhi >= -1.0f) && (ylo <= 1.0f) &&
+                          (c1 >= c0) && (r1 >= r0);
+    if (onscreen) {
+      box = make_int2((int)c0 | ((int)c1 << 16), (int)r0 | ((int)r1 << 16));
+      // interpolated depth is affine in the pixel: pz = base + gx dx + gy dy ; lower bound over the box
+      const float da = r.cz - r.az, db = r.az - r.bz;
+      const float gx = r.inv_den * (da * r.e1y + db * r.e2y);
+      const float gy = -r.inv_den * (da * r.e1x + db * r.e2x);
+      const float base = r.inv_den * r.az * r.area;
+      float zl = base + fminf(gx * (xlo - r.ax), gx * (xhi - r.ax)) + fminf(gy * (ylo - r.ay), gy * (yhi - r.ay));
+      zl -= 1e-5f * fabsf(zl) + 1e-6f;
+      zlow = (zl == zl) ? zl : -__int_as_float(0x7f800000);
+    }
+  }
+  fbox[(size_t)n * m.F + f] = box;
+  fzlow[(size_t)n * m.F + f] = zlow;
+  fkey[(size_t)n * m.F + f] = ((unsigned long long)orderable(zlow) << 32) | (unsigned)f;
+}
+
+// 5a': per-frame depth sort of the face ids (bitonic in LDS; F <= 8192)
+constexpr int kSortCap = 8192;
+__global__ void __launch_bounds__(1024)
+sort_faces_kernel(int F, const unsigned long long* __restrict__ fkey, int* __restrict__ forder) {
+  __shared__ unsigned long long keys[kSortCap];
+  const int n = blockIdx.x;
+  int NP = 1;
+  while (NP < F) NP <<= 1;
+  for (int i = threadIdx.x; i < NP; i += 1024) keys[i] = (i < F) ? fkey[(size_t)n * F + i] : ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= NP; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < NP; i += 1024) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = keys[i], b = keys[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < F; i += 1024) forder[(size_t)n * F + i] = (int)(keys[i] & 0xffffffffu);
+}
+
+__device__ __forceinline__ bool box_overlaps(int2 b, int x0, int x1, int y0, int y1) {
+  const int c0 = b.x & 0xffff, c1 = b.x >> 16, r0 = b.y & 0xffff, r1 = b.y >> 16;
+  return (c0 <= c1) && (c0 <= x1) && (c1 >= x0) && (r0 <= y1) && (r1 >= y0);
+}
+
+// ordered (stable) compaction position inside a 256-thread block; returns position or -1, and total.
+__device__ __forceinline__ int block_compact_pos(bool flag, int* wave_cnt /*[4] LDS*/, int& total) {
+  const unsigned long long bal = __ballot(flag);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int before = __popcll(bal & ((1ull << lane) - 1ull));
+  __syncthreads();
+  if (lane == 0) wave_cnt[w] = __popcll(bal);
+  __syncthreads();
+  int off = 0;
+  total = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { if (i < w) off += wave_cnt[i]; total += wave_cnt[i]; }
+  return flag ? off + before : -1;
+}
+
+// 5b: deterministic binning.  One block per (64x64 px coarse bin, frame): scans every face in depth
+// order, keeps those touching the coarse bin in LDS, then emits one depth-ordered list per 16x16 tile.
+__global__ void __launch_bounds__(256)
+bin_kernel(int F, int S, int Tx /*tiles per row*/, const int2* __restrict__ fbox, const int* __restrict__ forder,
+           int* __restrict__ tcount, int* __restrict__ toff, int* __restrict__ tlist, int cap_per_frame,
+           int* __restrict__ cursor /*[M]*/, int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) int lfid[];     // [F] ids of faces touching this coarse bin
+  __shared__ int wave_cnt[4];
+  __shared__ int tile_cnt[16], tile_base[16];
+  const int n = blockIdx.y;
+  const int CBx = (S + 63) / 64;
+  const int cbx = blockIdx.x % CBx, cby = blockIdx.x / CBx;
+  const int X0 = cbx * 64, X1 = min(X0 + 63, S - 1), Y0 = cby * 64, Y1 = min(Y0 + 63, S - 1);
+  const int2* fb = fbox + (size_t)n * F;
+  const int* ord = forder + (size_t)n * F;
+  int count = 0;
+  for (int base = 0; base < F; base += 256) {
+    const int i = base + threadIdx.x;
+    int f = 0;
+    int2 b = make_int2(1, 1);
+    if (i < F) { f = ord[i]; b = fb[f]; }
+    const bool hit = (i < F) && box_overlaps(b, X0, X1, Y0, Y1);
+    int total;
+    const int pos = block_compact_pos(hit, wave_cnt, total);
+    if (hit) lfid[count + pos] = f;
+    count += total;
+  }
+  __syncthreads();
+  // fine tiles of this coarse bin: wave w handles tiles w, w+4, ...  (count pass, then fill pass)
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int tt = w; tt < 16; tt += 4) {
+    const int tx = cbx * 4 + (tt & 3), ty = cby * 4 + (tt >> 2);
+    int c = 0;
+    if (tx * 16 < S && ty * 16 < S) {
+      const int x0 = tx * 16, x1 = x0 + 15, y0 = ty * 16, y1 = y0 + 15;
+      for (int i = lane; i < count; i += 64) c += box_overlaps(fb[lfid[i]], x0, x1, y0, y1) ? 1 : 0;
+      c = (int)wave_sum((float)c);     // counts < 2^24: exact in float
+    }
+    if (lane == 0) tile_cnt[tt] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int i = 0; i < 16; ++i) tot += tile_cnt[i];
+    int base = tot > 0 ? atomicAdd(&cursor[n], tot) : 0;
+    if (base + tot > cap_per_frame) { atomicOr(status, SMALFIT_STATUS_BIN_OVERFLOW); base = -1; }
+    for (int i = 0; i < 16; ++i) {
+      tile_base[i] = base;
+      if (base >= 0) base += tile_cnt[i];
+    }
+  }
+  __syncthreads();
+  for (int tt = w; tt < 16; tt += 4) {
+    const int tx = cbx * 4 + (tt & 3), ty = cby * 4 + (tt >> 2);
+    if (!(tx * 16 < S && ty * 16 < S)) continue;
+    const int tile = ty * Tx + tx;
+    const int base = tile_base[tt];
+    if (lane == 0) {
+      tcount[(size_t)n * Tx * Tx + tile] = base >= 0 ? tile_cnt[tt] : 0;
+      toff[(size_t)n * Tx * Tx + tile] = base >= 0 ? base : 0;
+    }
+    if (base < 0 || tile_cnt[tt] == 0) continue;
+    const int x0 = tx * 16, x1 = x0 + 15, y0 = ty * 16, y1 = y0 + 15;
+    int* out = tlist + (size_t)n * cap_per_frame + base;
+    int written = 0;
+    for (int i0 = 0; i0 < count; i0 += 64) {
+      const int i = i0 + lane;
+      const bool hit = (i < count) && box_overlaps(fb[lfid[i]], x0, x1, y0, y1);
+      const unsigned long long bal = __ballot(hit);
+      if (hit) out[written + __popcll(bal & ((1ull << lane) - 1ull))] = lfid[i];
+      written += __popcll(bal);
+    }
+  }
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// 5c: forward.  One wave per 8x8 pixel quadrant of a 16x16 tile (blockIdx.x = tile*4 + quadrant).
+// sil = 1 - prod_{k in K nearest} (1 - p_k).  Also emits the silhouette-loss partial and, per pixel,
+// (gpix, zthr): gpix = dL/dsil * (-alpha/sigma) seeds the backward pass, zthr is the depth of the K-th
+// nearest candidate (+inf when the pixel has <= K candidates).
+__global__ void __launch_bounds__(64)
+raster_fwd_kernel(ModelDev m, int S, int Tx, int M, int window, float w_sil,
+                  const float* __restrict__ proj, const int2* __restrict__ fbox, const float* __restrict__ fzlow,
+                  const int* __restrict__ tcount, const int* __restrict__ toff,
+                  const int* __restrict__ tlist, int cap_per_frame,
+                  const float* __restrict__ tsil /*[M][S][S] or null*/,
+                  float* __restrict__ sil_out /*[M][S][S] or null*/,
+                  float2* __restrict__ gz /*[M][S][S] or null*/,
+                  float* __restrict__ quad_loss /*[M][4T] or null*/) {
+  __shared__ __attribute__((aligned(16))) FaceRec rec[64];
+  __shared__ float rzlow[64];
+  __shared__ float zk[kFacesPerPixel * 64];        // per-lane ascending depths of the nearest candidates
+  const int n = blockIdx.y, tile = blockIdx.x >> 2, q = blockIdx.x & 3;
+  const int tx = tile % Tx, ty = tile / Tx;
+  const int lane = threadIdx.x;
+  const int qx0 = tx * 16 + (q & 1) * 8, qy0 = ty * 16 + (q >> 1) * 8;
+  const int col = qx0 + (lane & 7), row = qy0 + (lane >> 3);
+  const float inv_s = 1.0f / (float)S;
+  const float px = pix_to_ndc(col, inv_s), py = pix_to_ndc(row, inv_s);
+  const int Vp = m.Vp;
+  const float* pv = proj + (size_t)n * 3 * Vp;
+  const int count = tcount[(size_t)n * Tx * Tx + tile];
+  const int* list = tlist + (size_t)n * cap_per_frame + toff[(size_t)n * Tx * Tx + tile];
+  const float INF = __int_as_float(0x7f800000);
+  constexpr int K = kFacesPerPixel;
+
+  // stage up to 64 faces of the tile list that touch this quadrant; returns how many were staged
+  auto stage = [&](int c0) -> int {
+    const int i = c0 + lane;
+    bool valid = false;
+    int f = 0;
+    if (i < count) {
+      f = list[i];
+      valid = box_overlaps(fbox[(size_t)n * m.F + f], qx0, qx0 + 7, qy0, qy0 + 7);
+    }
+    const unsigned long long bal = __ballot(valid);
+    if (valid) {
+      const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+      const int i0 = m.faces[f * 3], i1 = m.faces[f * 3 + 1], i2 = m.faces[f * 3 + 2];
+      FaceRec r;
+      make_face_rec(pv[i0], pv[Vp + i0], pv[2 * Vp + i0], pv[i1], pv[Vp + i1], pv[2 * Vp + i1],
+                    pv[i2], pv[Vp + i2], pv[2 * Vp + i2], r);
+      rec[pos] = r;
+      rzlow[pos] = fzlow[(size_t)n * m.F + f];
+    }
+    return __popcll(bal);
+  };
+
+  // ---- phase 1: running product + K smallest depths -------------------------------------------------
+  float alpha = 1.0f;
+  int cnt = 0;
+  bool done = false;
+  for (int c0 = 0; c0 < count && !done; c0 += 64) {
+    const int nf = stage(c0);
+    __syncthreads();
+    for (int k = 0; k < nf; ++k) {
+      if ((k & 7) == 0) {
+        // every lane already holds K candidates and nothing nearer can follow: stop
+        const float zK = (cnt >= K) ? zk[(K - 1) * 64 + lane] : INF;
+        if (rzlow[k] > wave_max(zK)) { done = true; break; }
+      }
+      PixEval e;
+      if (face_pixel_eval(rec[k], px, py, e)) {
+        alpha *= one_minus_prob(e.d);
+        if (cnt < K || e.pz < zk[(K - 1) * 64 + lane]) {
+          int i = cnt < K ? cnt : K - 1;
+          while (i > 0 && zk[(i - 1) * 64 + lane] > e.pz) { zk[i * 64 + lane] = zk[(i - 1) * 64 + lane]; --i; }
+          zk[i * 64 + lane] = e.pz;
+        }
+        ++cnt;
+      }
+    }
+    __syncthreads();
+  }
+  // cnt == K after an early stop is exact (everything skipped is farther); cnt > K needs the product redone
+  const bool over = cnt > K;
+  const float zthr = (cnt >= K) ? zk[(K - 1) * 64 + lane] : INF;
+  // ---- phase 2 (only where some pixel overflowed): product over candidates with pz <= zthr ------------
+  if (__ballot(over) != 0ull) {
+    float alpha2 = 1.0f;
+    const float zstop = wave_max(over ? zthr : -INF);
+    done = false;
+    for (int c0 = 0; c0 < count && !done; c0 += 64) {
+      const int nf = stage(c0);
+      __syncthreads();
+      for (int k = 0; k < nf; ++k) {
+        if (rzlow[k] > zstop) { done = true; break; }
+        PixEval e;
+        if (face_pixel_eval(rec[k], px, py, e) && e.pz <= zthr) alpha2 *= one_minus_prob(e.d);
+      }
+      __syncthreads();
+    }
+    if (over) alpha = alpha2;
+  }
+  float l = 0.f;
+  if (col < S && row < S) {
+    const size_t pi = ((size_t)n * S + row) * S + col;
+    const float sil = 1.0f - alpha;
+    if (sil_out) sil_out[pi] = sil;
+    float gx = 0.f;
+    if (tsil) {
+      const float diff = sil - tsil[pi];
+      l = fabsf(diff);
+      const int Bn = frame_window_size(n, M, window);
+      const float sgn = (diff > 0.f) ? 1.0f : ((diff < 0.f) ? -1.0f : 0.0f);
+      gx = -(w_sil / ((float)Bn * (float)S * (float)S)) * sgn * alpha * (1.0f / kSigma);
+    }
+    if (gz) gz[pi] = make_float2(gx, zthr);
+  }
+  if (quad_loss) {
+    l = wave_sum(l);
+    if (lane == 0) quad_loss[(size_t)n * Tx * Tx * 4 + blockIdx.x] = l;
+  }
+}
+
+// gz = (dsil * (-(1 - sil) / sigma), zthr)   (component API: arbitrary upstream gradient)
+__global__ void gpix_from_dsil_kernel(size_t total, const float* __restrict__ sil, const float* __restrict__ dsil,
+                                      float2* __restrict__ gz) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) gz[i].x = -dsil[i] * (1.0f - sil[i]) * (1.0f / kSigma);
+}
+
+// 5d: backward, face-parallel gather (deterministic, no atomics).  16 lanes per face sweep the face's
+// pixel box in 4x4 patches; d(signed dist^2)/d(vertex) flows through the nearest edge only.
+__global__ void __launch_bounds__(256)
+raster_bwd_kernel(ModelDev m, int S, const float* __restrict__ proj, const int2* __restrict__ fbox,
+                  const float2* __restrict__ gz, float* __restrict__ dface /*[M][F][6]*/) {
+  const int n = blockIdx.y;
+  const int f = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int sub = threadIdx.x & 15, lx = sub & 3, ly = sub >> 2;
+  float ga[2] = {0.f, 0.f}, gb[2] = {0.f, 0.f}, gc[2] = {0.f, 0.f};
+  if (f < m.F) {
+    const int2 box = fbox[(size_t)n * m.F + f];
+    const int c0 = box.x & 0xffff, c1 = box.x >> 16, r0 = box.y & 0xffff, r1 = box.y >> 16;
+    if (c0 <= c1) {
+      const int Vp = m.Vp;
+      const float* pv = proj + (size_t)n * 3 * Vp;
+      const int i0 = m.faces[f * 3], i1 = m.faces[f * 3 + 1], i2 = m.faces[f * 3 + 2];
+      FaceRec r;
+      make_face_rec(pv[i0], pv[Vp + i0], pv[2 * Vp + i0], pv[i1], pv[Vp + i1], pv[2 * Vp + i1],
+                    pv[i2], pv[Vp + i2], pv[2 * Vp + i2], r);
+      const float inv_s = 1.0f / (float)S;
+      const float2* gp = gz + (size_t)n * S * S;
+      for (int ry = r0; ry <= r1; ry += 4) {
+        const int row = ry + ly;
+        for (int cx = c0; cx <= c1; cx += 4) {
+          const int col = cx + lx;
+          if (row > r1 || col > c1) continue;
+          const float2 g = gp[row * S + col];
+          if (g.x == 0.f) continue;
+          PixEval e;
+          if (!face_pixel_eval(r, pix_to_ndc(col, inv_s), pix_to_ndc(row, inv_s), e)) continue;
+          if (e.pz > g.y) continue;                 // not among the pixel's K nearest
+          // dL/dd = gpix * p ;  d = -+dist ;  d dist/d(u) = -2 q (1 - tc), d dist/d(w) = -2 q tc
+          const float gd = g.x * prob(e.d) * (e.inside ? -1.0f : 1.0f) * -2.0f;
+          const float ku = 1.0f - e.tc, kw = e.tc;
+          const float ca = (e.edge == 2) ? 0.f : ku;
+          const float cb = (e.edge == 0) ? kw : ((e.edge == 2) ? ku : 0.f);
+          const float cc = (e.edge == 0) ? 0.f : kw;
+          const float gx = gd * e.qx, gy = gd * e.qy;
+          ga[0] = fmaf(ca, gx, ga[0]); ga[1] = fmaf(ca, gy, ga[1]);
+          gb[0] = fmaf(cb, gx, gb[0]); gb[1] = fmaf(cb, gy, gb[1]);
+          gc[0] = fmaf(cc, gx, gc[0]); gc[1] = fmaf(cc, gy, gc[1]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    ga[0] += __shfl_xor(ga[0], o, 64); ga[1] += __shfl_xor(ga[1], o, 64);
+    gb[0] += __shfl_xor(gb[0], o, 64); gb[1] += __shfl_xor(gb[1], o, 64);
+    gc[0] += __shfl_xor(gc[0], o, 64); gc[1] += __shfl_xor(gc[1], o, 64);
+  }
+  if (f < m.F && sub == 0) {
+    float* o = dface + ((size_t)n * m.F + f) * 6;
+    o[0] = ga[0]; o[1] = ga[1]; o[2] = gb[0]; o[3] = gb[1]; o[4] = gc[0]; o[5] = gc[1];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: vertex adjoint: gather raster grads of incident faces, camera adjoint, joint-regressor adjoint,
+//     skinning adjoint wrt v_posed.   block = 256 vertices x FRB frames
+// ------------------------------------------------------------------------------------------------
+template <int FRB>
+__global__ void __launch_bounds__(256)
+vertex_bwd_kernel(ModelDev m, int M, const float* __restrict__ proj, const float* __restrict__ dface,
+                  const float* __restrict__ dJ41 /*[M][41][3] or null*/,
+                  const float* __restrict__ dverts_ext /*[M][3][Vp] extra world-space adjoint or null*/,
+                  const float* __restrict__ Am, float* __restrict__ dvert /*[M][3][Vp]*/,
+                  float* __restrict__ dvp /*[M][3][Vp]*/, float* __restrict__ dtr_part /*[VT][M][3]*/) {
+  __shared__ float As[FRB][420];
+  __shared__ float dJs[FRB][123];
+  __shared__ float red[16];
+  const int Vp = m.Vp;
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  const int n0 = blockIdx.y * FRB;
+  for (int i = threadIdx.x; i < FRB * 420; i += 256) {
+    const int f = i / 420;
+    As[f][i % 420] = (n0 + f < M) ? Am[(size_t)(n0 + f) * 420 + (i % 420)] : 0.f;
+  }
+  for (int i = threadIdx.x; i < FRB * 123; i += 256) {
+    const int f = i / 123;
+    dJs[f][i % 123] = (dJ41 && n0 + f < M) ? dJ41[(size_t)(n0 + f) * 123 + (i % 123)] : 0.f;
+  }
+  __syncthreads();
+  int lm = -1;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) if (v == m.landmarks[i]) lm = i;
+  const bool live = v < m.V;
+  for (int f = 0; f < FRB; ++f) {
+    const int n = n0 + f;
+    if (n >= M) break;
+    float g[3] = {0.f, 0.f, 0.f};       // adjoint of translated world vertex (raster path)
+    if (live && dface) {
+      float gxn = 0.f, gyn = 0.f;
+      const float* df = dface + (size_t)n * m.F * 6;
+      for (int i = m.vf_off[v]; i < m.vf_off[v + 1]; ++i) {
+        const int fc = m.vf_idx[i];                  // face*3 + corner
+        gxn += df[fc * 2];
+        gyn += df[fc * 2 + 1];
+      }
+      const float* pv = proj + (size_t)n * 3 * Vp;
+      world_to_ndc_bwd(pv[v], pv[Vp + v], pv[2 * Vp + v], gxn, gyn, g[0], g[1], g[2]);
+    }
+    if (live && dverts_ext) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) g[a] += dverts_ext[((size_t)n * 3 + a) * Vp + v];
+    }
+    // translation adjoint: sum over vertices of the translated-vertex adjoint
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float s = block_sum(live ? g[a] : 0.f, red);
+      if (threadIdx.x == 0) dtr_part[((size_t)blockIdx.x * M + n) * 3 + a] = s;
+    }
+    // joints = J_regressor^T verts  (+ landmark picks)
+    float dv[3] = {g[0], g[1], g[2]};
+    if (live) {
+      for (int e = 0; e < m.Kj; ++e) {
+        const int j = m.jrv_j[e * Vp + v];
+        const float c = m.jrv_val[e * Vp + v];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) dv[a] = fmaf(c, dJs[f][j * 3 + a], dv[a]);
+      }
+      if (lm >= 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) dv[a] += dJs[f][(35 + lm) * 3 + a];
+      }
+    }
+    // skinning: vert = T.R vp + T.t  ->  dvp = T.R^T dv
+    float T[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) T[e] = 0.f;
+    if (live) {
+      for (int e = 0; e < m.Kw; ++e) {
+        const int j = m.w_j[e * Vp + v];
+        const float wv = m.w_val[e * Vp + v];
+        const float* A = &As[f][j * 12];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) T[a * 3 + b] = fmaf(wv, A[a * 4 + b], T[a * 3 + b]);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const float o = T[b] * dv[0] + T[3 + b] * dv[1] + T[6 + b] * dv[2];
+      if (v < Vp) {
+        dvp[((size_t)n * 3 + b) * Vp + v] = live ? o : 0.f;
+        dvert[((size_t)n * 3 + b) * Vp + v] = live ? dv[b] : 0.f;
+      }
+    }
+  }
+}
+
+// K7: dA[n][j] = sum over the skin-weight column of joint j of  w * dvert (x) [v_posed; 1]
+__global__ void __launch_bounds__(128)
+dA_kernel(ModelDev m, const float* __restrict__ dvert, const float* __restrict__ vposed,
+          float* __restrict__ dA /*[M][35][12]*/) {
+  __shared__ float red[16];
+  const int j = blockIdx.x, n = blockIdx.y, Vp = m.Vp;
+  const float* dv = dvert + (size_t)n * 3 * Vp;
+  const float* vp = vposed + (size_t)n * 3 * Vp;
+  float acc[12];
+#pragma unroll
+  for (int e = 0; e < 12; ++e) acc[e] = 0.f;
+  for (int i = m.wc_off[j] + threadIdx.x; i < m.wc_off[j + 1]; i += 128) {
+    const int v = m.wc_v[i];
+    const float wv = m.wc_val[i];
+    const float p[4] = {vp[v], vp[Vp + v], vp[2 * Vp + v], 1.0f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float d = wv * dv[a * Vp + v];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a * 4 + b] = fmaf(d, p[b], acc[a * 4 + b]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 12; ++e) {
+    const float s = block_sum(acc[e], red);
+    if (threadIdx.x == 0) dA[((size_t)n * 35 + j) * 12 + e] = s;
+  }
+}
+
+// K8: pose-blend adjoint  dpf[n][k] = sum_col dvp[n][col] * pd[k][col]   (split over columns)
+// one wave = 16 frames x 8 pose features, lanes stride the 3*Vp columns of its column split.
+constexpr int PB_NT = 16, PB_KT = 8;
+__global__ void __launch_bounds__(64)
+poseblend_bwd_kernel(ModelDev m, int M, int CS, const float* __restrict__ dvp,
+                     float* __restrict__ dpf_part /*[CS][M][308]*/) {
+  const int k0 = blockIdx.x * PB_KT, n0 = blockIdx.y * PB_NT, cs = blockIdx.z;
+  const int lane = threadIdx.x;
+  const int ncol = 3 * m.Vp;
+  const int chunk = ((ncol / 64 + CS - 1) / CS) * 64;
+  const int cbeg = cs * chunk, cend = min(ncol, cbeg + chunk);
+  float acc[PB_NT][PB_KT];
+#pragma unroll
+  for (int i = 0; i < PB_NT; ++i)
+#pragma unroll
+    for (int k = 0; k < PB_KT; ++k) acc[i][k] = 0.f;
+  for (int c = cbeg + lane; c < cend; c += 64) {
+    float p[PB_KT], d[PB_NT];
+#pragma unroll
+    for (int k = 0; k < PB_KT; ++k) p[k] = (k0 + k < 306) ? m.pd[(size_t)(k0 + k) * ncol + c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < PB_NT; ++i) d[i] = (n0 + i < M) ? dvp[(size_t)(n0 + i) * ncol + c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < PB_NT; ++i)
+#pragma unroll
+      for (int k = 0; k < PB_KT; ++k) acc[i][k] = fmaf(d[i], p[k], acc[i][k]);
+  }
+#pragma unroll
+  for (int i = 0; i < PB_NT; ++i)
+#pragma unroll
+    for (int k = 0; k < PB_KT; ++k) {
+      const float s = wave_sum(acc[i][k]);
+      if (lane == 0 && n0 + i < M && k0 + k < 306)
+        dpf_part[((size_t)cs * M + n0 + i) * 308 + k0 + k] = s;
+    }
+}
+
+// K9: shape-blend adjoint.  shared betas: dbeta_part[block][b] = sum_col sd[b][col] * sum_n dvp[n][col]
+//     per-frame betas (blockIdx.y = frame): no sum over frames.
+__global__ void __launch_bounds__(256)
+dbeta_kernel(ModelDev m, int M, int nb, int shared, const float* __restrict__ dvp,
+             float* __restrict__ dbeta_part /*[nbs][gridDim.x][nb]*/) {
+  __shared__ float red[16];
+  const int ncol = 3 * m.Vp;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  float g = 0.f;
+  if (c < ncol) {
+    if (shared) for (int n = 0; n < M; ++n) g += dvp[(size_t)n * ncol + c];
+    else g = dvp[(size_t)blockIdx.y * ncol + c];
+  }
+  for (int b = 0; b < nb; ++b) {
+    const float s = block_sum((c < ncol) ? g * m.sd[(size_t)b * ncol + c] : 0.f, red);
+    if (threadIdx.x == 0) dbeta_part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * nb + b] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K10: per-frame chain adjoint: dA, dpf -> d theta, d logscale, d rest joints
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+chain_bwd_kernel(ModelDev m, int M, const float* __restrict__ theta, const float* __restrict__ Rm,
+                 const float* __restrict__ Gm, const float* __restrict__ scm,
+                 const float* __restrict__ Jrest, int j_stride, const float* __restrict__ dA,
+                 const float* __restrict__ dpf_part, int CS, const float* __restrict__ dth_direct,
+                 float* __restrict__ dtheta /*[M][105]*/, float* __restrict__ dls /*[M][6]*/,
+                 float* __restrict__ dJrest /*[M][105]*/) {
+  __shared__ float R[35][9], G[35][12], sc[35][3], J[35][3];
+  __shared__ float dG[35][12], dR[35][9], dsc[35][3], dJ[35][3];
+  __shared__ float dRp[9], dj[3];
+  __shared__ int par[35];
+  const int n = blockIdx.x, l = threadIdx.x;
+  for (int i = l; i < 315; i += 64) R[i / 9][i % 9] = Rm[(size_t)n * 315 + i];
+  for (int i = l; i < 420; i += 64) G[i / 12][i % 12] = Gm[(size_t)n * 420 + i];
+  for (int i = l; i < 105; i += 64) {
+    sc[i / 3][i % 3] = scm[(size_t)n * 105 + i];
+    J[i / 3][i % 3] = Jrest[(size_t)n * j_stride + i];
+    dsc[i / 3][i % 3] = 0.f;
+  }
+  if (l < 35) par[l] = m.parents[l];
+  // pose-feature adjoint -> dR of joints 1..34 ; root starts at 0
+  for (int i = l; i < 315; i += 64) {
+    float s = 0.f;
+    if (i >= 9 && dpf_part) for (int c = 0; c < CS; ++c) s += dpf_part[((size_t)c * M + n) * 308 + (i - 9)];
+    dR[i / 9][i % 9] = s;
+  }
+  __syncthreads();
+  // A_j = [G.R | G.t - G.R J_j]
+  for (int i = l; i < 420; i += 64) {
+    const int j = i / 12, e = i % 12, a = e >> 2, b = e & 3;
+    const float* da = dA + ((size_t)n * 35 + j) * 12;
+    dG[j][e] = (b < 3) ? da[e] - da[a * 4 + 3] * J[j][b] : da[e];
+  }
+  for (int i = l; i < 105; i += 64) {
+    const int j = i / 3, c = i % 3;
+    const float* da = dA + ((size_t)n * 35 + j) * 12;
+    dJ[j][c] = -(G[j][0 * 4 + c] * da[3] + G[j][1 * 4 + c] * da[7] + G[j][2 * 4 + c] * da[11]);
+  }
+  __syncthreads();
+  for (int i = 34; i >= 1; --i) {
+    const int p = par[i];
+    // phase 1: dR' = G_p.R^T dG_i.R ; dj = G_p.R^T dG_i.t
+    if (l < 9) {
+      const int a = l / 3, b = l % 3;
+      dRp[l] = G[p][0 * 4 + a] * dG[i][0 * 4 + b] + G[p][1 * 4 + a] * dG[i][1 * 4 + b] + G[p][2 * 4 + a] * dG[i][2 * 4 + b];
+    } else if (l < 12) {
+      const int a = l - 9;
+      dj[a] = G[p][0 * 4 + a] * dG[i][3] + G[p][1 * 4 + a] * dG[i][7] + G[p][2 * 4 + a] * dG[i][11];
+    }
+    __syncthreads();
+    // phase 2: accumulate into the parent and the local rotation / scales / joints
+    if (l < 9) {
+      const int a = l / 3, c = l % 3;
+      // dG_p.R[a][c] += sum_b dG_i.R[a][b] R'[c][b] + dG_i.t[a] (J_i - J_p)[c]
+      float acc = dG[i][a * 4 + 3] * (J[i][c] - J[p][c]);
+#pragma unroll
+      for (int b = 0; b < 3; ++b) acc = fmaf(dG[i][a * 4 + b], R[i][c * 3 + b] * sc[i][b] / sc[p][c], acc);
+      dG[p][a * 4 + c] += acc;
+      // dR_i[a][c] += dR'[a][c] s_i[c] / s_p[a]
+      dR[i][a * 3 + c] += dRp[a * 3 + c] * sc[i][c] / sc[p][a];
+    } else if (l < 12) {
+      const int a = l - 9;
+      dG[p][a * 4 + 3] += dG[i][a * 4 + 3];
+      dJ[i][a] += dj[a];
+      dJ[p][a] -= dj[a];
+    } else if (l < 15) {
+      const int b = l - 12;       // ds_i[b] += sum_a dR'[a][b] R_i[a][b] / s_p[a]
+      float acc = 0.f;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) acc = fmaf(dRp[a * 3 + b], R[i][a * 3 + b] / sc[p][a], acc);
+      dsc[i][b] += acc;
+    }
+    __syncthreads();
+    if (l < 3) {
+      const int a = l;            // ds_p[a] -= sum_b dR'[a][b] R'[a][b] / s_p[a]
+      float acc = 0.f;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) acc = fmaf(dRp[a * 3 + b], R[i][a * 3 + b] * sc[i][b] / sc[p][a], acc);
+      dsc[p][a] -= acc / sc[p][a];
+    }
+    __syncthreads();
+  }
+  if (l < 9) dR[0][l] += dG[0][(l / 3) * 4 + (l % 3)];
+  if (l < 3) dJ[0][l] += dG[0][l * 4 + 3];
+  __syncthreads();
+  if (l < 35) {
+    const float th[3] = {theta[(n * 35 + l) * 3], theta[(n * 35 + l) * 3 + 1], theta[(n * 35 + l) * 3 + 2]};
+    float g[9], d[3];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) g[e] = dR[l][e];
+    rodrigues_bwd(th, g, d);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      dtheta[(size_t)n * 105 + l * 3 + a] = d[a] + (dth_direct ? dth_direct[(size_t)n * 105 + l * 3 + a] : 0.f);
+  }
+  if (l < 6 && dls) {
+    float acc = 0.f;
+    for (int i = 0; i < 105; ++i)
+      if (m.scale_idx[i] == l) acc += dsc[i / 3][i % 3] * sc[i / 3][i % 3];
+    dls[(size_t)n * 6 + l] = acc;
+  }
+  for (int i = l; i < 105; i += 64) dJrest[(size_t)n * 105 + i] = dJ[i / 3][i % 3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K11: gradient assembly (single block): shared-parameter reductions, masks, loss totals
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+assemble_kernel(AssembleArgs a) {
+  const int t = threadIdx.x;
+  const int M = a.M;
+  // betas: sum of column-block partials + sum_n JS^T dJrest[n] + prior
+  if (a.g_betas) {
+    const int nbs = a.betas_shared ? 1 : M;
+    for (int idx = t; idx < nbs * a.nb; idx += 256) {
+      const int s = idx / a.nb, b = idx % a.nb;
+      float acc = 0.f;
+      for (int blk = 0; blk < a.nblk_beta; ++blk) acc += a.dbeta_part[((size_t)s * a.nblk_beta + blk) * a.nb + b];
+      const int nlo = a.betas_shared ? 0 : s, nhi = a.betas_shared ? M : s + 1;
+      for (int n = nlo; n < nhi; ++n)
+        for (int i = 0; i < 105; ++i) acc = fmaf(a.dJrest[(size_t)n * 105 + i], a.JS[i * a.NBall + b], acc);
+      if (a.gb_prior && s == 0) acc += a.gb_prior[b];
+      a.g_betas[idx] = acc;
+    }
+  }
+  if (a.g_ls) {
+    if (a.ls_shared) {
+      if (t < 6) {
+        float acc = 0.f;
+        for (int n = 0; n < M; ++n) acc += a.dls[(size_t)n * 6 + t];
+        if (a.gls_prior) acc += a.gls_prior[t];
+        a.g_ls[t] = acc;
+      }
+    } else {
+      for (int i = t; i < M * 6; i += 256) a.g_ls[i] = a.dls[i];
+    }
+  }
+  for (int i = t; i < M * 3; i += 256) {
+    const int n = i / 3, e = i % 3;
+    if (a.g_grot) a.g_grot[i] = a.dtheta[(size_t)n * 105 + e] * a.gmask[e];
+    if (a.g_trans) {
+      float acc = a.dtr_direct ? a.dtr_direct[i] : 0.f;
+      for (int vt = 0; vt < a.nvt; ++vt) acc += a.dtr_part[((size_t)vt * M + n) * 3 + e];
+      a.g_trans[i] = acc;
+    }
+  }
+  if (a.g_jrot)
+    for (int i = t; i < M * 102; i += 256) {
+      const int n = i / 102, e = i % 102;
+      a.g_jrot[i] = a.dtheta[(size_t)n * 105 + 3 + e] * a.rmask[e];
+    }
+  // losses: [joint, pose, splay, betas, sil, temp_joint, temp_global, temp_trans]
+  if (a.losses && t < 8) {
+    float acc = 0.f;
+    if (t == 3) acc = a.loss_betas ? *a.loss_betas : 0.f;
+    else if (t == 4) {
+      if (a.tile_loss) {
+        for (int n = 0; n < M; ++n) {
+          float s = 0.f;
+          for (int k = 0; k < a.T; ++k) s += a.tile_loss[(size_t)n * a.T + k];
+          const int Bn = frame_window_size(n, M, a.window);
+          acc += s * a.w_sil / ((float)Bn * (float)a.S * (float)a.S);
+        }
+      }
+    } else if (a.loss_part) {
+      for (int n = 0; n < M; ++n) acc += a.loss_part[n * 8 + t];
+    }
+    a.losses[t] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K12: Adam (torch.optim.Adam semantics: eps outside the bias-corrected sqrt)
+// ------------------------------------------------------------------------------------------------
+__global__ void adam_kernel(int count, float* __restrict__ p, const float* __restrict__ g,
+                            float* __restrict__ mm, float* __restrict__ vv,
+                            float step_size, float b1, float b2, float eps, float bc2_sqrt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const float gi = g[i];
+  const float mi = b1 * mm[i] + (1.0f - b1) * gi;
+  const float vi = b2 * vv[i] + (1.0f - b2) * gi * gi;
+  mm[i] = mi;
+  vv[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] = p[i] - step_size * (mi / denom);
+}
+
+// ------------------------------------------------------------------------------------------------
+// temporal term on its own (SMALFitter.get_temporal called outside forward): M frames, one block
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128)
+temporal_kernel(int M, float w_temp, const float* __restrict__ theta, const float* __restrict__ trans,
+                float* __restrict__ losses /*[3] joint, global, trans*/, float* __restrict__ dtheta /*[M][105]*/,
+                float* __restrict__ dtrans /*[M][3]*/) {
+  __shared__ float red[16];
+  const int t = threadIdx.x;
+  float lj = 0.f, lg = 0.f, lt = 0.f;
+  for (int idx = t; idx < M * 108; idx += 128) {
+    const int n = idx / 108, e = idx % 108;
+    const bool is_tr = e >= 105;
+    const int k = is_tr ? e - 105 : e;
+    const float D = is_tr ? 3.0f : (k < 3 ? 3.0f : 102.0f);
+    const float cur = is_tr ? trans[n * 3 + k] : theta[n * 105 + k];
+    float g = 0.f;
+    if (n + 1 < M) {
+      const float d = cur - (is_tr ? trans[(n + 1) * 3 + k] : theta[(n + 1) * 105 + k]);
+      const float term = d * d * (w_temp / D);
+      if (is_tr) lt += term; else if (k < 3) lg += term; else lj += term;
+      g += d;
+    }
+    if (n > 0) g += cur - (is_tr ? trans[(n - 1) * 3 + k] : theta[(n - 1) * 105 + k]);
+    g *= 2.0f * w_temp / D;
+    if (is_tr) dtrans[n * 3 + k] = g; else dtheta[n * 105 + k] = g;
+  }
+  lj = block_sum(lj, red); lg = block_sum(lg, red); lt = block_sum(lt, red);
+  if (t == 0) { losses[0] = lj; losses[1] = lg; losses[2] = lt; }
+}
+
+// apply masks to a (M,105) theta adjoint -> grads of global_rotation (M,3) and joint_rotations (M,102)
+__global__ void split_theta_grad_kernel(int M, const float* __restrict__ dtheta, const float* __restrict__ gmask,
+                                        const float* __restrict__ rmask, float* __restrict__ g_grot,
+                                        float* __restrict__ g_jrot) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * 105) return;
+  const int n = i / 105, e = i % 105;
+  if (e < 3) { if (g_grot) g_grot[n * 3 + e] = dtheta[i] * (gmask ? gmask[e] : 1.f); }
+  else if (g_jrot) g_jrot[n * 102 + e - 3] = dtheta[i] * (rmask ? rmask[e - 3] : 1.f);
+}
+
+// keypoint projection for arbitrary points (Renderer.forward points branch) + adjoint
+__global__ void project_points_kernel(int count, int S, const float* __restrict__ pts, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float xn, yn, zv;
+  world_to_ndc(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], xn, yn, zv);
+  const float half = 0.5f * (float)(S - 1);
+  out[i * 2] = half * (1.0f - yn);
+  out[i * 2 + 1] = half * (1.0f - xn);
+}
+__global__ void project_points_bwd_kernel(int count, int S, const float* __restrict__ pts,
+                                          const float* __restrict__ dout, float* __restrict__ dpts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float xn, yn, zv;
+  world_to_ndc(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], xn, yn, zv);
+  const float half = 0.5f * (float)(S - 1);
+  world_to_ndc_bwd(xn, yn, zv, -half * dout[i * 2 + 1], -half * dout[i * 2], dpts[i * 3], dpts[i * 3 + 1], dpts[i * 3 + 2]);
+}
+
+// Rodrigues on its own (batch_rodrigues drop-in) + adjoint
+__global__ void rodrigues_kernel(int count, const float* __restrict__ th, float* __restrict__ R) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float r[9];
+  const float t[3] = {th[i * 3], th[i * 3 + 1], th[i * 3 + 2]};
+  rodrigues_fwd(t, r);
+#pragma unroll
+  for (int e = 0; e < 9; ++e) R[i * 9 + e] = r[e];
+}
+__global__ void rodrigues_bwd_kernel(int count, const float* __restrict__ th, const float* __restrict__ dR,
+                                     float* __restrict__ dth) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const float t[3] = {th[i * 3], th[i * 3 + 1], th[i * 3 + 2]};
+  float g[9], d[3];
+#pragma unroll
+  for (int e = 0; e < 9; ++e) g[e] = dR[i * 9 + e];
+  rodrigues_bwd(t, g, d);
+  dth[i * 3] = d[0]; dth[i * 3 + 1] = d[1]; dth[i * 3 + 2] = d[2];
+}
+
+__global__ void zero_int_kernel(int count, int* p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) p[i] = 0;
+}
+
+}  // namespace smalfit
+
+#include "smalfit_launch.inc"

@@ -1,0 +1,189 @@
+// Per-element maths of the SMAL fitting path, shared by every kernel in smalfit_kernels.hip.
+// Functions are SMALFIT_HD (= __host__ __device__ under hipcc, plain inline under g++) so that
+// tests/host_math_check.cpp can finite-difference them on the CPU; the product only ever calls them
+// from device code.
+//
+// Reference behaviour restated here (file:line into /root/reference):
+//   rodrigues_fwd / _bwd        smal_model/batch_lbs.py:9-52       (angle = ||theta + 1e-8||)
+//   chain step fwd / bwd        smal_model/batch_lbs.py:137-168
+//   camera                      smal_fitter/p3d_renderer.py:22-23  (dist 2.7, OpenGL persp fov 60)
+//   face_pixel_eval             pytorch3d 0.2.5 RasterizeMeshesNaiveCpu + sigmoid_alpha_blend
+//                               (p3d_renderer.py:26-39,66)
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define SMALFIT_HD __host__ __device__ __forceinline__
+#else
+#define SMALFIT_HD inline
+#endif
+
+namespace smalfit {
+
+constexpr int kJoints = 35;
+constexpr int kPoseFeat = 306;
+constexpr int kModelJoints = 41;
+constexpr int kKeypoints = 25;
+constexpr int kLogScales = 6;
+
+constexpr float kCamDist = 2.7f;
+constexpr float kCamScale = 1.7320508075688772f;   // 1 / tan(30 deg)
+constexpr float kSigma = 1e-4f;
+constexpr float kBlur = 9.21024036697585e-4f;       // log(1/1e-4 - 1) * 1e-4
+constexpr float kBlurSqrt = 0.030348377826444f;
+constexpr float kEps = 1e-8f;                       // pytorch3d kEpsilon
+constexpr int kFacesPerPixel = 100;
+
+// ------------------------------------------------------------------------------------------------
+// Rodrigues
+// ------------------------------------------------------------------------------------------------
+SMALFIT_HD void rodrigues_fwd(const float th[3], float R[9]) {
+  const float ux = th[0] + 1e-8f, uy = th[1] + 1e-8f, uz = th[2] + 1e-8f;
+  const float a = sqrtf(ux * ux + uy * uy + uz * uz);
+  const float ia = 1.0f / a;
+  const float rx = th[0] * ia, ry = th[1] * ia, rz = th[2] * ia;
+  const float c = cosf(a), s = sinf(a), k = 1.0f - c;
+  R[0] = c + k * rx * rx;      R[1] = k * rx * ry - s * rz; R[2] = k * rx * rz + s * ry;
+  R[3] = k * ry * rx + s * rz; R[4] = c + k * ry * ry;      R[5] = k * ry * rz - s * rx;
+  R[6] = k * rz * rx - s * ry; R[7] = k * rz * ry + s * rx; R[8] = c + k * rz * rz;
+}
+
+// dth = (dR/dth)^T G following the reference's computational graph (finite at th = 0).
+SMALFIT_HD void rodrigues_bwd(const float th[3], const float G[9], float dth[3]) {
+  const float ux = th[0] + 1e-8f, uy = th[1] + 1e-8f, uz = th[2] + 1e-8f;
+  const float a = sqrtf(ux * ux + uy * uy + uz * uz);
+  const float ia = 1.0f / a;
+  const float r[3] = {th[0] * ia, th[1] * ia, th[2] * ia};
+  const float c = cosf(a), s = sinf(a), k = 1.0f - c;
+  // Gr = G r, GTr = G^T r
+  float Gr[3], GTr[3];
+  for (int i = 0; i < 3; ++i) {
+    Gr[i] = G[3 * i] * r[0] + G[3 * i + 1] * r[1] + G[3 * i + 2] * r[2];
+    GTr[i] = G[i] * r[0] + G[3 + i] * r[1] + G[6 + i] * r[2];
+  }
+  const float rGr = r[0] * Gr[0] + r[1] * Gr[1] + r[2] * Gr[2];
+  const float trG = G[0] + G[4] + G[8];
+  const float kv[3] = {G[7] - G[5], G[2] - G[6], G[3] - G[1]};     // d<G,[r]x>/dr
+  const float dc = trG - rGr;
+  const float ds = r[0] * kv[0] + r[1] * kv[1] + r[2] * kv[2];
+  float dr[3];
+  for (int i = 0; i < 3; ++i) dr[i] = k * (Gr[i] + GTr[i]) + s * kv[i];
+  const float da = -s * dc + c * ds - (dr[0] * r[0] + dr[1] * r[1] + dr[2] * r[2]) * ia;
+  dth[0] = dr[0] * ia + da * ux * ia;
+  dth[1] = dr[1] * ia + da * uy * ia;
+  dth[2] = dr[2] * ia + da * uz * ia;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 helpers (row-major)
+// ------------------------------------------------------------------------------------------------
+SMALFIT_HD void mat3_mul(const float A[9], const float B[9], float C[9]) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+SMALFIT_HD void mat3_vec(const float A[9], const float v[3], float o[3]) {
+  for (int i = 0; i < 3; ++i) o[i] = A[3 * i] * v[0] + A[3 * i + 1] * v[1] + A[3 * i + 2] * v[2];
+}
+SMALFIT_HD void mat3T_vec(const float A[9], const float v[3], float o[3]) {
+  for (int i = 0; i < 3; ++i) o[i] = A[i] * v[0] + A[3 + i] * v[1] + A[6 + i] * v[2];
+}
+
+// ------------------------------------------------------------------------------------------------
+// camera: world -> (x_ndc, y_ndc, z_view) and its adjoint
+// ------------------------------------------------------------------------------------------------
+SMALFIT_HD void world_to_ndc(float x, float y, float z, float& xn, float& yn, float& zv) {
+  zv = kCamDist - z;
+  const float iz = kCamScale / zv;
+  xn = -x * iz;
+  yn = y * iz;
+}
+SMALFIT_HD void world_to_ndc_bwd(float xn, float yn, float zv, float gxn, float gyn,
+                                 float& gx, float& gy, float& gz) {
+  const float iz = 1.0f / zv;
+  gx = -kCamScale * iz * gxn;
+  gy = kCamScale * iz * gyn;
+  gz = (xn * gxn + yn * gyn) * iz;
+}
+
+// ------------------------------------------------------------------------------------------------
+// soft-silhouette per (pixel, face) evaluation
+// ------------------------------------------------------------------------------------------------
+// Face record, 20 floats, laid out for five 16-byte LDS broadcasts.
+struct FaceRec {
+  float ax, ay, e1x, e1y;        // a, e1 = b - a
+  float e2x, e2y, e3x, e3y;      // e2 = c - a, e3 = c - b
+  float il1, il2, il3, area;     // 1/|e|^2 per edge (0 when degenerate), signed area E(c; a, b)
+  float t01, t02, t03, inv_den;  // t offsets (1 when the edge is degenerate: distance to its end point)
+  float az, bz, cz, pad;
+};
+
+// returns false when the face is culled as a whole (degenerate area or entirely behind the camera)
+SMALFIT_HD bool make_face_rec(float ax, float ay, float az, float bx, float by, float bz,
+                              float cx, float cy, float cz, FaceRec& r) {
+  r.ax = ax; r.ay = ay;
+  r.e1x = bx - ax; r.e1y = by - ay;
+  r.e2x = cx - ax; r.e2y = cy - ay;
+  r.e3x = cx - bx; r.e3y = cy - by;
+  const float l1 = r.e1x * r.e1x + r.e1y * r.e1y;
+  const float l2 = r.e2x * r.e2x + r.e2y * r.e2y;
+  const float l3 = r.e3x * r.e3x + r.e3y * r.e3y;
+  r.il1 = l1 > kEps ? 1.0f / l1 : 0.0f;  r.t01 = l1 > kEps ? 0.0f : 1.0f;
+  r.il2 = l2 > kEps ? 1.0f / l2 : 0.0f;  r.t02 = l2 > kEps ? 0.0f : 1.0f;
+  r.il3 = l3 > kEps ? 1.0f / l3 : 0.0f;  r.t03 = l3 > kEps ? 0.0f : 1.0f;
+  r.area = r.e2x * r.e1y - r.e2y * r.e1x;            // E(c; a, b) = (c-a) x (b-a)
+  r.inv_den = 1.0f / (r.area + kEps);
+  r.az = az; r.bz = bz; r.cz = cz; r.pad = 0.0f;
+  const float zmax = fmaxf(az, fmaxf(bz, cz));
+  return (fabsf(r.area) > kEps) && (zmax >= 0.0f);
+}
+
+struct PixEval {
+  float d;        // signed squared distance (negative inside)
+  float pz;       // interpolated view-space depth at the pixel
+  float qx, qy;   // p - closest point on the nearest edge
+  float tc;       // clamped parameter on that edge
+  int edge;       // 0: a-b, 1: a-c, 2: b-c
+  bool inside;
+};
+
+// true when the face contributes to pixel centre (px, py) (pytorch3d naive rasteriser inclusion test)
+SMALFIT_HD bool face_pixel_eval(const FaceRec& r, float px, float py, PixEval& o) {
+  const float dx = px - r.ax, dy = py - r.ay;
+  const float c1 = dx * r.e1y - dy * r.e1x;          // E(p; a, b)
+  const float c2 = dx * r.e2y - dy * r.e2x;          // -E(p; c, a)
+  const float w2 = c1 * r.inv_den;
+  const float w1 = -c2 * r.inv_den;
+  const float w0 = (c2 - c1 + r.area) * r.inv_den;   // E(p; b, c) / (area + eps)
+  o.inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
+  const float pz = w0 * r.az + w1 * r.bz + w2 * r.cz;
+  o.pz = pz;
+  // edge a-b
+  float t1 = fminf(fmaxf((dx * r.e1x + dy * r.e1y) * r.il1 + r.t01, 0.0f), 1.0f);
+  const float q1x = dx - t1 * r.e1x, q1y = dy - t1 * r.e1y;
+  const float d1 = q1x * q1x + q1y * q1y;
+  // edge a-c
+  float t2 = fminf(fmaxf((dx * r.e2x + dy * r.e2y) * r.il2 + r.t02, 0.0f), 1.0f);
+  const float q2x = dx - t2 * r.e2x, q2y = dy - t2 * r.e2y;
+  const float d2 = q2x * q2x + q2y * q2y;
+  // edge b-c
+  const float ex = dx - r.e1x, ey = dy - r.e1y;
+  float t3 = fminf(fmaxf((ex * r.e3x + ey * r.e3y) * r.il3 + r.t03, 0.0f), 1.0f);
+  const float q3x = ex - t3 * r.e3x, q3y = ey - t3 * r.e3y;
+  const float d3 = q3x * q3x + q3y * q3y;
+  float dist = d1; o.qx = q1x; o.qy = q1y; o.tc = t1; o.edge = 0;
+  if (d2 < dist) { dist = d2; o.qx = q2x; o.qy = q2y; o.tc = t2; o.edge = 1; }
+  if (d3 < dist) { dist = d3; o.qx = q3x; o.qy = q3y; o.tc = t3; o.edge = 2; }
+  o.d = o.inside ? -dist : dist;
+  return (pz >= 0.0f) && (o.inside || dist < kBlur);
+}
+
+// 1 - p = sigmoid(d / sigma)
+SMALFIT_HD float one_minus_prob(float d) { return 1.0f / (1.0f + expf(-d * (1.0f / kSigma))); }
+// p = sigmoid(-d / sigma)
+SMALFIT_HD float prob(float d) { return 1.0f / (1.0f + expf(d * (1.0f / kSigma))); }
+
+// pixel centre in NDC (both image axes flipped)
+SMALFIT_HD float pix_to_ndc(int i, float inv_s) { return 1.0f - (2.0f * (float)i + 1.0f) * inv_s; }
+
+}  // namespace smalfit

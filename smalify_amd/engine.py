@@ -1,0 +1,233 @@
+"""Thin object layer over the C-ABI: device model, workspace engine, typed calls on torch tensors.
+
+PyTorch is plumbing here (HBM allocations, streams); every computation is a HIP kernel in
+libsmalfit.so.  All tensors handed to these methods must be contiguous float32 CUDA(HIP) tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import FitArgs, ModelDesc, SmalfitError, check
+
+LOSS_NAMES = ("joint", "pose", "splay", "betas", "sil_reproj", "temp_joint", "temp_global", "temp_trans")
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise SmalfitError("expected a contiguous float32 device tensor, got %r" % (
+            (t.dtype, t.device, t.is_contiguous()) if isinstance(t, torch.Tensor) else type(t),))
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _host(a, dtype):
+    return np.ascontiguousarray(np.asarray(a), dtype=dtype)
+
+
+class DeviceModel:
+    """SMAL constants resident in HBM (smalfit_model)."""
+
+    def __init__(self, model_data):
+        if not torch.cuda.is_available():
+            raise SmalfitError("no HIP device available: smalify_amd has no CPU fallback")
+        self.lib = _lib.load()
+        md = model_data
+        self.data = md
+        self.num_verts = int(md.v_template.shape[0])
+        self.num_faces = int(md.faces.shape[0])
+        self.num_betas = int(md.shapedirs.shape[0])
+        keep = dict(vt=_host(md.v_template, np.float32), sd=_host(md.shapedirs, np.float32),
+                    pd=_host(md.posedirs, np.float32), jr=_host(md.J_regressor, np.float32),
+                    w=_host(md.weights, np.float32), par=_host(md.parents, np.int32),
+                    f=_host(md.faces, np.int32))
+        desc = ModelDesc(self.num_verts, self.num_faces, self.num_betas,
+                         keep["vt"].ctypes.data, keep["sd"].ctypes.data, keep["pd"].ctypes.data,
+                         keep["jr"].ctypes.data, keep["w"].ctypes.data, keep["par"].ctypes.data,
+                         keep["f"].ctypes.data)
+        torch.cuda.init()
+        torch.cuda.current_device()
+        h = C.c_void_p()
+        check(self.lib.smalfit_model_create(C.byref(desc), C.byref(h)), "smalfit_model_create")
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.smalfit_model_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class Engine:
+    """Workspace for up to `max_frames` frames at `image_size`^2 (smalfit_engine)."""
+
+    def __init__(self, model: DeviceModel, max_frames: int, image_size: int):
+        self.lib = model.lib
+        self.model = model
+        self.max_frames = int(max_frames)
+        self.image_size = int(image_size)
+        h = C.c_void_p()
+        check(self.lib.smalfit_engine_create(model.handle, self.max_frames, self.image_size, C.byref(h)),
+              "smalfit_engine_create")
+        self.handle = h
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.smalfit_engine_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ---- priors ------------------------------------------------------------------------------
+    def set_pose_prior(self, prec, mean, mask):
+        p, m, k = _host(prec, np.float32), _host(mean, np.float32), _host(mask, np.float32)
+        assert p.shape == (105, 105) and m.shape == (105,) and k.shape == (105,)
+        check(self.lib.smalfit_engine_set_pose_prior(self.handle, p.ctypes.data, m.ctypes.data, k.ctypes.data),
+              "smalfit_engine_set_pose_prior")
+
+    def set_shape_prior(self, prec, mean):
+        p, m = _host(prec, np.float32), _host(mean, np.float32)
+        assert p.shape == (m.shape[0], m.shape[0])
+        check(self.lib.smalfit_engine_set_shape_prior(self.handle, p.ctypes.data, m.ctypes.data, int(m.shape[0])),
+              "smalfit_engine_set_shape_prior")
+        self.shape_prior_dim = int(m.shape[0])
+
+    def status(self):
+        """Synchronises the current stream; returns and clears the sticky status bits."""
+        bits = C.c_int(0)
+        check(self.lib.smalfit_engine_status(self.handle, _stream(), C.byref(bits)), "smalfit_engine_status")
+        return bits.value
+
+    # ---- fused fitter evaluation ---------------------------------------------------------------
+    def fit_eval(self, *, betas, log_beta_scales, global_rotation, joint_rotations, trans,
+                 target_joints, target_visibility, target_sil, weights, w_temp, window,
+                 temporal=True, global_mask=None, rotation_mask=None, halo_prev=None, halo_next=None,
+                 losses=None, grads=None, want=("betas", "log_beta_scales", "global_rotation",
+                                                "joint_rotations", "trans"),
+                 sil_out=None, proj_out=None, verts_out=None):
+        """One evaluation of sum_windows SMALFitter.forward + get_temporal and its gradient.
+
+        weights = (w_j2d, w_sil, w_betas, w_pose, w_limit (ignored), w_splay) as in the reference's
+        OPT_WEIGHTS columns.  Returns (losses (8,) device tensor, grads dict)."""
+        M = int(global_rotation.shape[0])
+        w_j2d, w_sil, w_betas, w_pose, _w_limit, w_splay = [float(w) for w in weights]
+        dev = global_rotation.device
+        if losses is None:
+            losses = torch.empty(8, device=dev, dtype=torch.float32)
+        if grads is None:
+            grads = {}
+        params = dict(betas=betas, log_beta_scales=log_beta_scales, global_rotation=global_rotation,
+                      joint_rotations=joint_rotations, trans=trans)
+        for k in want:
+            if k not in grads and params[k] is not None:
+                grads[k] = torch.empty_like(params[k])
+        if log_beta_scales is None:
+            mode = 0
+        elif log_beta_scales.dim() == 1:
+            mode = 1
+        else:
+            mode = 2
+        a = FitArgs()
+        a.num_frames, a.window, a.logscale_mode, a.temporal = M, int(window), mode, int(bool(temporal))
+        a.shape_prior_dim = 0
+        a.w_j2d, a.w_sil, a.w_betas, a.w_pose, a.w_splay, a.w_temp = w_j2d, w_sil, w_betas, w_pose, w_splay, float(w_temp)
+        a.betas, a.log_beta_scales = _ptr(betas), _ptr(log_beta_scales)
+        a.global_rotation, a.joint_rotations, a.trans = _ptr(global_rotation), _ptr(joint_rotations), _ptr(trans)
+        a.global_mask, a.rotation_mask = _ptr(global_mask), _ptr(rotation_mask)
+        a.target_joints, a.target_visibility, a.target_sil = _ptr(target_joints), _ptr(target_visibility), _ptr(target_sil)
+        a.halo_prev, a.halo_next = _ptr(halo_prev), _ptr(halo_next)
+        a.losses = _ptr(losses)
+        a.g_betas = _ptr(grads.get("betas")) if "betas" in want else None
+        a.g_log_beta_scales = _ptr(grads.get("log_beta_scales")) if "log_beta_scales" in want else None
+        a.g_global_rotation = _ptr(grads.get("global_rotation")) if "global_rotation" in want else None
+        a.g_joint_rotations = _ptr(grads.get("joint_rotations")) if "joint_rotations" in want else None
+        a.g_trans = _ptr(grads.get("trans")) if "trans" in want else None
+        a.sil_out, a.proj_out, a.verts_out = _ptr(sil_out), _ptr(proj_out), _ptr(verts_out)
+        check(self.lib.smalfit_fit_eval(self.handle, _stream(), C.byref(a)), "smalfit_fit_eval")
+        return losses, grads
+
+    # ---- SMAL.__call__ ---------------------------------------------------------------------------
+    def lbs_forward(self, beta, theta, logscale=None, want_Rs=True, want_v_shaped=True):
+        M, nb = int(theta.shape[0]), int(beta.shape[1])
+        V = self.model.num_verts
+        dev = theta.device
+        verts = torch.empty(M, V, 3, device=dev)
+        joints = torch.empty(M, 41, 3, device=dev)
+        Rs = torch.empty(M, 35, 3, 3, device=dev) if want_Rs else None
+        vs = torch.empty(M, V, 3, device=dev) if want_v_shaped else None
+        check(self.lib.smalfit_lbs_forward(self.handle, _stream(), M, nb, _ptr(beta), _ptr(theta), _ptr(logscale),
+                                           _ptr(verts), _ptr(joints), _ptr(Rs), _ptr(vs)), "smalfit_lbs_forward")
+        return verts, joints, Rs, vs
+
+    def lbs_backward(self, beta, theta, logscale, dverts, djoints):
+        M, nb = int(theta.shape[0]), int(beta.shape[1])
+        dev = theta.device
+        dbeta = torch.empty(M, nb, device=dev)
+        dtheta = torch.empty(M, 35, 3, device=dev)
+        dls = torch.empty(M, 6, device=dev) if logscale is not None else None
+        check(self.lib.smalfit_lbs_backward(self.handle, _stream(), M, nb, _ptr(beta), _ptr(theta), _ptr(logscale),
+                                            _ptr(dverts), _ptr(djoints), _ptr(dbeta), _ptr(dtheta), _ptr(dls)),
+              "smalfit_lbs_backward")
+        return dbeta, dtheta, dls
+
+    # ---- Renderer -----------------------------------------------------------------------------------
+    def render_forward(self, verts, points=None, want_sil=True):
+        M = int(verts.shape[0])
+        S = self.image_size
+        sil = torch.empty(M, S, S, device=verts.device) if want_sil else None
+        proj = None
+        P = 0
+        if points is not None:
+            P = int(points.shape[1])
+            proj = torch.empty(M, P, 2, device=verts.device)
+        check(self.lib.smalfit_render_forward(self.handle, _stream(), M, _ptr(verts), _ptr(points), P, _ptr(sil),
+                                              _ptr(proj)), "smalfit_render_forward")
+        return sil, proj
+
+    def render_backward(self, verts, sil, dsil):
+        dverts = torch.empty_like(verts)
+        check(self.lib.smalfit_render_backward(self.handle, _stream(), int(verts.shape[0]), _ptr(verts), _ptr(sil),
+                                               _ptr(dsil), _ptr(dverts)), "smalfit_render_backward")
+        return dverts
+
+    def project_points_backward(self, points, dproj):
+        dpoints = torch.empty_like(points)
+        count = int(points.numel() // 3)
+        check(self.lib.smalfit_project_points_backward(_stream(), count, self.image_size, _ptr(points), _ptr(dproj),
+                                                       _ptr(dpoints)), "smalfit_project_points_backward")
+        return dpoints
+
+
+def rodrigues(theta):
+    lib = _lib.load()
+    count = int(theta.shape[0])
+    R = torch.empty(count, 3, 3, device=theta.device)
+    check(lib.smalfit_rodrigues(_stream(), count, _ptr(theta), _ptr(R)), "smalfit_rodrigues")
+    return R
+
+
+def rodrigues_backward(theta, dR):
+    lib = _lib.load()
+    count = int(theta.shape[0])
+    dth = torch.empty_like(theta)
+    check(lib.smalfit_rodrigues_backward(_stream(), count, _ptr(theta), _ptr(dR), _ptr(dth)), "smalfit_rodrigues_backward")
+    return dth
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, t, beta1=0.5, beta2=0.999, eps=1e-8):
+    """In-place torch.optim.Adam step on a flat float32 device tensor (reference optimize_to_joints.py:96,137)."""
+    lib = _lib.load()
+    check(lib.smalfit_adam_step(_stream(), int(param.numel()), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                float(lr), float(beta1), float(beta2), float(eps), int(t)), "smalfit_adam_step")

@@ -1,0 +1,256 @@
+"""Parity cases HIP-vs-oracle, shared by tests/test_gpu_parity.py (asserting) and tools/gpu_diag.py
+(printing).  Every function returns {metric_name: value}; nothing here asserts.
+
+Oracle = oracle/smal_oracle.py in float64 (test infrastructure).  HIP = smalify_amd through the C-ABI.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from oracle import smal_oracle as so
+from smalify_amd import config as cfg
+from smalify_amd import engine as eng
+from smalify_amd import model_io, synthetic
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32).cuda()
+
+
+_CACHE = {}
+
+
+def get_model(dense=False):
+    key = ("model", dense)
+    if key not in _CACHE:
+        md = synthetic.synthetic_model(seed=0, shape_family_id=1, dense_weights=dense)
+        _CACHE[key] = (md, so.OracleModel(md), eng.DeviceModel(md))
+    return _CACHE[key]
+
+
+def get_engine(max_frames, S, dense=False):
+    key = ("engine", max_frames, S, dense)
+    if key not in _CACHE:
+        _, _, dm = get_model(dense)
+        e = eng.Engine(dm, max_frames, S)
+        pp = synthetic.synthetic_pose_prior()
+        sp = synthetic.synthetic_shape_prior()
+        e.set_pose_prior(*pp)
+        e.set_shape_prior(*sp)
+        _CACHE[key] = (e, pp, sp)
+    return _CACHE[key]
+
+
+def random_pose(M, seed, scale=1.0, z=1.45):
+    rs = np.random.RandomState(seed)
+    init = model_io.initial_global_rotation()
+    return dict(
+        betas=(0.4 * rs.randn(20)).astype(np.float32),
+        log_beta_scales=(0.15 * rs.randn(6)).astype(np.float32),
+        global_rotation=(init[None] + 0.25 * scale * rs.randn(M, 3)).astype(np.float32),
+        joint_rotations=(0.2 * scale * rs.randn(M, 34, 3)).astype(np.float32),
+        trans=(np.array([0.03, -0.02, z])[None] + 0.03 * rs.randn(M, 3)).astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------------------
+def case_rodrigues():
+    rs = np.random.RandomState(3)
+    th = rs.randn(64, 3).astype(np.float32)
+    th[0] = 0
+    th[1] = [1e-6, -2e-6, 3e-6]
+    th[2] = [3.1, 0, 0]
+    G = rs.randn(64, 3, 3).astype(np.float32)
+    R = eng.rodrigues(dev(th)).cpu().numpy()
+    dth = eng.rodrigues_backward(dev(th), dev(G)).cpu().numpy()
+    t64 = torch.from_numpy(th).double().requires_grad_(True)
+    Ro = so.rodrigues(t64)
+    (Ro * torch.from_numpy(G).double()).sum().backward()
+    return {"rodrigues_fwd_maxabs": float(np.abs(R - Ro.detach().numpy()).max()),
+            "rodrigues_bwd_rel": rel(dth, t64.grad.numpy()),
+            "rodrigues_bwd_zero_row_abs": float(np.abs(dth[0] - t64.grad.numpy()[0]).max())}
+
+
+def case_lbs(M=3, dense=False, with_scale=True):
+    md, om, _ = get_model(dense)
+    e, _, _ = get_engine(8, 64, dense)
+    rs = np.random.RandomState(5)
+    beta = (0.5 * rs.randn(M, 20)).astype(np.float32)
+    theta = (0.3 * rs.randn(M, 35, 3)).astype(np.float32)
+    theta[0, 3:] = 0.0                       # a frame with exactly-zero joint rotations
+    ls = (0.2 * rs.randn(M, 6)).astype(np.float32) if with_scale else None
+    wv = rs.randn(M, md.num_verts, 3).astype(np.float32)
+    wj = rs.randn(M, 41, 3).astype(np.float32)
+    v, j, Rs, vs = e.lbs_forward(dev(beta), dev(theta), dev(ls) if with_scale else None)
+    db, dt, dl = e.lbs_backward(dev(beta), dev(theta), dev(ls) if with_scale else None, dev(wv), dev(wj))
+    b64 = torch.from_numpy(beta).double().requires_grad_(True)
+    t64 = torch.from_numpy(theta).double().requires_grad_(True)
+    l64 = torch.from_numpy(ls).double().requires_grad_(True) if with_scale else None
+    vo, jo, Ro, vso = so.smal_forward(om, b64, t64, l64)
+    ((vo * torch.from_numpy(wv).double()).sum() + (jo * torch.from_numpy(wj).double()).sum()).backward()
+    out = {"lbs_verts_rel": rel(v.cpu(), vo.detach()), "lbs_joints_rel": rel(j.cpu(), jo.detach()),
+           "lbs_Rs_rel": rel(Rs.cpu(), Ro.detach()), "lbs_vshaped_rel": rel(vs.cpu(), vso.detach()),
+           "lbs_dbeta_rel": rel(db.cpu(), b64.grad), "lbs_dtheta_rel": rel(dt.cpu(), t64.grad)}
+    if with_scale:
+        out["lbs_dlogscale_rel"] = rel(dl.cpu(), l64.grad)
+    return out
+
+
+def _sil_metrics(sil_hip, sil_or):
+    d = np.abs(np.asarray(sil_hip, np.float64) - np.asarray(sil_or, np.float64))
+    return {"sil_maxabs": float(d.max()), "sil_meanabs": float(d.mean()),
+            "sil_frac_gt_1e-4": float((d > 1e-4).mean()), "sil_frac_gt_1e-3": float((d > 1e-3).mean())}
+
+
+def case_render(M=2, S=64, z=1.45, seed=11):
+    md, om, _ = get_model()
+    e, _, _ = get_engine(8, S)
+    p = random_pose(M, seed, z=z)
+    theta = np.concatenate([p["global_rotation"][:, None], p["joint_rotations"]], 1)
+    with torch.no_grad():
+        vo, jo, _, _ = so.smal_forward(om, torch.from_numpy(np.tile(p["betas"], (M, 1))).double(),
+                                       torch.from_numpy(theta).double(),
+                                       torch.from_numpy(np.tile(p["log_beta_scales"], (M, 1))).double())
+    verts = (vo + torch.from_numpy(p["trans"]).double()[:, None]).float()       # float32 inputs for both
+    pts = (jo + torch.from_numpy(p["trans"]).double()[:, None])[:, so.CANONICAL].float()
+    sil, proj = e.render_forward(verts.cuda().contiguous(), pts.cuda().contiguous())
+    status = e.status()
+    v64 = verts.double().requires_grad_(True)
+    sil_o, stats = so.soft_silhouette(v64, om.faces, S, return_stats=True)
+    rs = np.random.RandomState(seed + 1)
+    w = rs.randn(M, S, S).astype(np.float32)
+    (sil_o * torch.from_numpy(w).double()).sum().backward()
+    dverts = e.render_backward(verts.cuda().contiguous(), sil, dev(w)).cpu().numpy()
+    proj_o = so.project_points(pts.double(), S).numpy()
+    out = _sil_metrics(sil.cpu().numpy(), sil_o.detach().numpy())
+    out.update({"render_status": status, "render_oracle_max_faces_per_pixel": stats["max_faces_per_pixel"],
+                "render_coverage": float((sil_o > 0.5).double().mean()),
+                "render_dverts_rel": rel(dverts, v64.grad.numpy()),
+                "render_dverts_norm": float(np.linalg.norm(v64.grad.numpy())),
+                "render_proj_maxabs_px": float(np.abs(proj.cpu().numpy() - proj_o).max())})
+    return out
+
+
+def make_problem(M, S, window, seed=21, z=1.45, with_sil=True):
+    """Synthetic fitting problem: targets from a ground-truth pose, evaluation at a perturbed pose."""
+    md, om, _ = get_model()
+    e, pp, sp = get_engine(max(M, 8), S)
+    gt = random_pose(M, seed, z=z)
+    cur = random_pose(M, seed, z=z)
+    rs = np.random.RandomState(seed + 7)
+    cur["global_rotation"] += (0.05 * rs.randn(M, 3)).astype(np.float32)
+    cur["joint_rotations"] += (0.08 * rs.randn(M, 34, 3)).astype(np.float32)
+    cur["trans"] += (0.02 * rs.randn(M, 3)).astype(np.float32)
+    cur["betas"] += (0.1 * rs.randn(20)).astype(np.float32)
+    with torch.no_grad():
+        theta = np.concatenate([gt["global_rotation"][:, None], gt["joint_rotations"]], 1)
+        vo, jo, _, _ = so.smal_forward(om, torch.from_numpy(np.tile(gt["betas"], (M, 1))).double(),
+                                       torch.from_numpy(theta).double(),
+                                       torch.from_numpy(np.tile(gt["log_beta_scales"], (M, 1))).double())
+        t = torch.from_numpy(gt["trans"]).double()[:, None]
+        tj = so.project_points((jo + t)[:, so.CANONICAL], S).numpy() + rs.randn(M, 25, 2)
+        if with_sil:
+            tsil = (so.soft_silhouette(vo + t, om.faces, S) > 0.5).double().numpy()
+        else:
+            tsil = np.zeros((M, S, S))
+    vis = (rs.rand(M, 25) < 0.85).astype(np.float32)
+    vis[:, [2, 5, 8]] = 1.0
+    prob = so.FitProblem(om, S, tj, vis, tsil, pp[0], pp[1], pp[2], sp[0], sp[1], window, use_unity_prior=True)
+    return e, prob, cur, dict(tj=tj.astype(np.float32), vis=vis, tsil=tsil.astype(np.float32))
+
+
+def case_fit(M=4, S=64, window=2, stage=2, seed=21, trainable=None):
+    W = np.array(cfg.OPT_WEIGHTS).T
+    weights = W[stage][:6].copy()
+    w_temp = float(W[stage][6])
+    with_sil = weights[1] > 0
+    e, prob, cur, tg = make_problem(M, S, window, seed, with_sil=with_sil)
+    if trainable is None:
+        trainable = so.trainable_names(stage)
+    vis = tg["vis"]
+    vis_o = None
+    if stage == 0:
+        vis_o = so.stage0_visibility(torch.from_numpy(vis).double())
+        vis = vis_o.numpy().astype(np.float32)
+    params64 = {k: torch.from_numpy(v).double() for k, v in cur.items()}
+    total, sums, grads_o = so.loss_and_grads(prob, params64, weights, w_temp, trainable, vis_o)
+    d = {k: dev(v) for k, v in cur.items()}
+    losses, grads = e.fit_eval(betas=d["betas"], log_beta_scales=d["log_beta_scales"],
+                               global_rotation=d["global_rotation"], joint_rotations=d["joint_rotations"],
+                               trans=d["trans"], target_joints=dev(tg["tj"]), target_visibility=dev(vis),
+                               target_sil=dev(tg["tsil"]), weights=weights, w_temp=w_temp, window=window,
+                               want=trainable)
+    status = e.status()
+    l = losses.cpu().numpy().astype(np.float64)
+    names = ("joint", "pose", "splay", "betas", "sil_reproj", "temp_joint", "temp_global", "temp_trans")
+    out = {"fit_status": status, "fit_total_rel": abs(l.sum() - float(total)) / abs(float(total)),
+           "fit_total_oracle": float(total)}
+    for i, nme in enumerate(names):
+        ref = sums.get(nme, 0.0)
+        out["fit_loss_%s_abs" % nme] = abs(l[i] - ref)
+        out["fit_loss_%s_oracle" % nme] = ref
+    for k in trainable:
+        out["fit_grad_%s_rel" % k] = rel(grads[k].cpu().numpy(), grads_o[k].numpy())
+        out["fit_grad_%s_norm" % k] = float(np.linalg.norm(grads_o[k].numpy()))
+    return out
+
+
+def case_fit_golden(golden, tag, window, stage):
+    """HIP fitter evaluation against the *reference's own* outputs (tests/golden, no silhouette)."""
+    md, _, dm = get_model()
+    S = int(golden["g6_image_size"])
+    N = golden["g6_target_joints"].shape[0]
+    key = ("golden_engine", S)
+    if key not in _CACHE:
+        e = eng.Engine(dm, 8, S)
+        e.set_pose_prior(golden["pose_prec"], golden["pose_mean"], golden["pose_mask"])
+        e.set_shape_prior(golden["unity_prec"], golden["unity_mean"])
+        _CACHE[key] = e
+    e = _CACHE[key]
+    weights = golden["g6_w0"] if stage == 0 else golden["g6_w1"]
+    w_temp = float(golden["g6_wtemp"][stage])
+    vis = golden["g6_visibility"].astype(np.float32)
+    if stage == 0:
+        v0 = np.zeros_like(vis)
+        v0[:, cfg.TORSO_JOINTS] = vis[:, cfg.TORSO_JOINTS]
+        vis = v0
+    p = {k: dev(golden["%s_p_%s" % (tag, k)]) for k in
+         ("betas", "log_beta_scales", "global_rotation", "joint_rotations", "trans")}
+    trainable = ("global_rotation", "trans") if stage == 0 else so.PARAM_ORDER
+    losses, grads = e.fit_eval(betas=p["betas"], log_beta_scales=p["log_beta_scales"],
+                               global_rotation=p["global_rotation"], joint_rotations=p["joint_rotations"],
+                               trans=p["trans"], target_joints=dev(golden["g6_target_joints"]),
+                               target_visibility=dev(vis), target_sil=None, weights=weights, w_temp=w_temp,
+                               window=window, want=trainable)
+    l = losses.cpu().numpy().astype(np.float64)
+    out = {"golden_total_rel": abs(l.sum() - float(golden[tag + "_total"])) / abs(float(golden[tag + "_total"]))}
+    for i, nme in enumerate(("joint", "pose", "splay", "betas")):
+        key = "%s_term_%s" % (tag, nme)
+        if key in golden:
+            out["golden_loss_%s_rel" % nme] = abs(l[i] - float(golden[key])) / max(abs(float(golden[key])), 1e-12)
+    t = golden[tag + "_temporal"]
+    out["golden_temporal_rel"] = rel(l[5:8], t)
+    for k in trainable:
+        out["golden_grad_%s_rel" % k] = rel(grads[k].cpu().numpy(), golden["%s_g_%s" % (tag, k)])
+    return out
+
+
+def case_adam():
+    rs = np.random.RandomState(9)
+    p0 = rs.randn(1000).astype(np.float32)
+    p = dev(p0)
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    po = {"x": torch.from_numpy(p0).double()}
+    opt = so.Adam(["x"], lr=5e-3)
+    for t in range(1, 6):
+        g = rs.randn(1000).astype(np.float32) * (10.0 ** rs.randint(-3, 3))
+        eng.adam_step(p, dev(g), m, v, 5e-3, t)
+        opt.step(po, {"x": torch.from_numpy(g).double()})
+    return {"adam_rel": rel(p.cpu().numpy(), po["x"].numpy())}
