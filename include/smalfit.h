@@ -28,8 +28,7 @@ typedef struct smalfit_engine smalfit_engine;
 #define SMALFIT_NUM_KEYPOINTS 25
 #define SMALFIT_NUM_LOSS_TERMS 8 /* joint, pose, splay, betas, sil_reproj, temp_joint, temp_global, temp_trans */
 
-#define SMALFIT_STATUS_BIN_OVERFLOW 1
-#define SMALFIT_STATUS_K_OVERFLOW 2
+#define SMALFIT_STATUS_BIN_OVERFLOW 1 /* reserved */
 
 int smalfit_version(void);
 const char* smalfit_last_error(void);
@@ -59,6 +58,18 @@ int smalfit_engine_create(smalfit_model* model, int max_frames, int image_size, 
 void smalfit_engine_destroy(smalfit_engine* engine);
 /* synchronises `stream`, returns and clears the sticky status bits (SMALFIT_STATUS_*) */
 int smalfit_engine_status(smalfit_engine* engine, void* stream, int* status_bits);
+
+/* optional: time sections of smalfit_fit_eval with HIP events recorded on the caller's stream.
+ * profile_begin arms up to max_evals evaluations; profile_end synchronises `stream`, and returns the summed
+ * milliseconds and the number of timed evaluations per section. */
+#define SMALFIT_NUM_SECTIONS 5
+#define SMALFIT_SEC_LBS_FWD 0    /* shape + pose + skin + joints kernels          */
+#define SMALFIT_SEC_RASTER_BIN 1 /* face boxes + raster_sweep_kernel (count, log-alpha) */
+#define SMALFIT_SEC_RASTER_FWD 2 /* raster_resolve_kernel (K-nearest product)     */
+#define SMALFIT_SEC_RASTER_BWD 3 /* raster_bwd_kernel alone                       */
+#define SMALFIT_SEC_LBS_BWD 4    /* vertex / dA / pose-blend / chain adjoints     */
+int smalfit_engine_profile_begin(smalfit_engine* engine, int max_evals);
+int smalfit_engine_profile_end(smalfit_engine* engine, void* stream, float* ms_total, int* counts);
 
 /* replaces: Prior.__init__ data              reference smal_fitter/priors/pose_prior_35.py:51-92
  * host arrays: prec (105,105), mean (105), mask (105) */

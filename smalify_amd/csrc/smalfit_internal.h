@@ -4,8 +4,7 @@
 
 #include "smalfit_math.h"
 
-#define SMALFIT_STATUS_BIN_OVERFLOW 1   // tile lists exceeded the per-frame capacity
-#define SMALFIT_STATUS_K_OVERFLOW 2     // a pixel had more than 100 contributing faces (K cap not applied)
+#define SMALFIT_STATUS_BIN_OVERFLOW 1   // a frame's candidate-list pool overflowed
 
 namespace smalfit {
 

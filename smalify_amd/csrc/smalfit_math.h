@@ -115,8 +115,12 @@ struct FaceRec {
   float e2x, e2y, e3x, e3y;      // e2 = c - a, e3 = c - b
   float il1, il2, il3, area;     // 1/|e|^2 per edge (0 when degenerate), signed area E(c; a, b)
   float t01, t02, t03, inv_den;  // t offsets (1 when the edge is degenerate: distance to its end point)
-  float az, bz, cz, pad;
+  float pz0, gzx, gzy, pad;      // interpolated depth as a plane: pz = pz0 + gzx (px - ax) + gzy (py - ay)
 };
+
+// interpolated view-space depth of face r at pixel offset (dx, dy) = p - a.  This exact expression is the
+// definition of pz everywhere (inclusion test, K-nearest selection, backward), so comparisons agree bitwise.
+SMALFIT_HD float face_depth(const FaceRec& r, float dx, float dy) { return fmaf(r.gzy, dy, fmaf(r.gzx, dx, r.pz0)); }
 
 // returns false when the face is culled as a whole (degenerate area or entirely behind the camera)
 SMALFIT_HD bool make_face_rec(float ax, float ay, float az, float bx, float by, float bz,
@@ -133,7 +137,12 @@ SMALFIT_HD bool make_face_rec(float ax, float ay, float az, float bx, float by, 
   r.il3 = l3 > kEps ? 1.0f / l3 : 0.0f;  r.t03 = l3 > kEps ? 0.0f : 1.0f;
   r.area = r.e2x * r.e1y - r.e2y * r.e1x;            // E(c; a, b) = (c-a) x (b-a)
   r.inv_den = 1.0f / (r.area + kEps);
-  r.az = az; r.bz = bz; r.cz = cz; r.pad = 0.0f;
+  // pz = w0 az + w1 bz + w2 cz with barycentrics over (area + eps) is affine in the pixel
+  const float da = cz - az, db = az - bz;
+  r.gzx = r.inv_den * (da * r.e1y + db * r.e2y);
+  r.gzy = -r.inv_den * (da * r.e1x + db * r.e2x);
+  r.pz0 = r.inv_den * az * r.area;
+  r.pad = 0.0f;
   const float zmax = fmaxf(az, fmaxf(bz, cz));
   return (fabsf(r.area) > kEps) && (zmax >= 0.0f);
 }
@@ -156,7 +165,7 @@ SMALFIT_HD bool face_pixel_eval(const FaceRec& r, float px, float py, PixEval& o
   const float w1 = -c2 * r.inv_den;
   const float w0 = (c2 - c1 + r.area) * r.inv_den;   // E(p; b, c) / (area + eps)
   o.inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
-  const float pz = w0 * r.az + w1 * r.bz + w2 * r.cz;
+  const float pz = face_depth(r, dx, dy);
   o.pz = pz;
   // edge a-b
   float t1 = fminf(fmaxf((dx * r.e1x + dy * r.e1y) * r.il1 + r.t01, 0.0f), 1.0f);
@@ -182,6 +191,14 @@ SMALFIT_HD bool face_pixel_eval(const FaceRec& r, float px, float py, PixEval& o
 SMALFIT_HD float one_minus_prob(float d) { return 1.0f / (1.0f + expf(-d * (1.0f / kSigma))); }
 // p = sigmoid(-d / sigma)
 SMALFIT_HD float prob(float d) { return 1.0f / (1.0f + expf(d * (1.0f / kSigma))); }
+
+// log2(1 - p) = log2 sigmoid(x), x = d / sigma, accurate for |x| large or small:
+// logsigmoid(x) = min(x, 0) - log1p(exp(-|x|)).  Clamped at -256 (alpha underflows to 0 long before).
+SMALFIT_HD float log2_one_minus_prob(float d) {
+  const float x = d * (1.0f / kSigma);
+  const float ls = fminf(x, 0.0f) - log1pf(expf(-fabsf(x)));
+  return fmaxf(ls * 1.4426950408889634f, -256.0f);
+}
 
 // pixel centre in NDC (both image axes flipped)
 SMALFIT_HD float pix_to_ndc(int i, float inv_s) { return 1.0f - (2.0f * (float)i + 1.0f) * inv_s; }

@@ -1,0 +1,210 @@
+"""Fused fitting loop: the reference's optimize_to_joints stage/epoch loop with every tensor resident
+in HBM and every arithmetic step a HIP kernel (smalfit_fit_eval + smalfit_adam_step).
+
+Reference semantics reproduced (file:line into /root/reference):
+  * parameters and their initial values          smal_fitter/smal_fitter.py:48-97
+  * 4-stage schedule from OPT_WEIGHTS            config.py:63-72, smal_fitter/optimize_to_joints.py:90-94
+  * new Adam(lr, betas=(0.5, 0.999)) per stage   optimize_to_joints.py:96
+  * stage 0 trains global_rotation + trans only, torso keypoints only   optimize_to_joints.py:98-104
+  * per epoch: sum over windows + temporal, one backward, one step      optimize_to_joints.py:113-137
+  * per-frame checkpoint dict                    smal_fitter.py:213-219, optimize_to_joints.py:46-48
+
+Differences by design: all windows of an epoch are evaluated in one launch sequence (the per-window
+normalisers are applied per frame, the sum over windows is identical); nothing synchronises with the
+host inside the loop (the reference reads 4 device scalars per epoch for tqdm).
+"""
+from __future__ import annotations
+
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from . import config
+from . import engine as eng
+from . import model_io
+from . import smal_topology as topo
+
+PARAM_NAMES = ("betas", "log_beta_scales", "joint_rotations", "global_rotation", "trans")
+
+
+class FusedFitter:
+    """Owns the fit parameters of N frames in one flat HBM buffer laid out as
+    [betas(20) | log_beta_scales(6 or N*6) | joint_rotations(N*102) | global_rotation(N*3) | trans(N*3)]
+    so that the stage-0 trainable set (global_rotation, trans) is one contiguous Adam segment."""
+
+    def __init__(self, engine: eng.Engine, target_joints, target_visibility, target_sil, window_size,
+                 use_unity_prior=True, mean_betas=None, mean_log_scales=None, allow_limb_scaling=True,
+                 rank=0, world_size=1, group=None):
+        self.e = engine
+        dev = engine.device
+        self.N = int(target_joints.shape[0])
+        self.S = engine.image_size
+        self.window = int(window_size)
+        self.unity = bool(use_unity_prior)
+        self.allow_limb_scaling = allow_limb_scaling
+        self.rank, self.world_size, self.group = rank, world_size, group
+        f32 = dict(device=dev, dtype=torch.float32)
+
+        def to_dev(x):
+            if not isinstance(x, torch.Tensor):
+                x = torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+            return x.to(**f32).contiguous()
+
+        self.target_joints = to_dev(target_joints)
+        self.visibility_full = to_dev(target_visibility)
+        self.target_sil = to_dev(target_sil).reshape(self.N, self.S, self.S).contiguous()
+        vis0 = torch.zeros_like(self.visibility_full)
+        vis0[:, config.TORSO_JOINTS] = self.visibility_full[:, config.TORSO_JOINTS]
+        self.visibility_stage0 = vis0.contiguous()
+
+        N = self.N
+        self.ls_shared = self.unity            # smal_fitter.py:61 vs :71-72
+        n_ls = 6 if self.ls_shared else N * 6
+        self.offsets = {}
+        off = 0
+        for name, count in (("betas", 20), ("log_beta_scales", n_ls), ("joint_rotations", N * 102),
+                            ("global_rotation", N * 3), ("trans", N * 3)):
+            self.offsets[name] = (off, count)
+            off += count
+        self.flat = torch.zeros(off, **f32)
+        self.grad = torch.zeros(off, **f32)
+        self.exp_avg = torch.zeros(off, **f32)
+        self.exp_avg_sq = torch.zeros(off, **f32)
+        shapes = dict(betas=(20,), log_beta_scales=(6,) if self.ls_shared else (N, 6),
+                      joint_rotations=(N, 34, 3), global_rotation=(N, 3), trans=(N, 3))
+        self.p = {k: self.flat[o:o + c].view(shapes[k]) for k, (o, c) in self.offsets.items()}
+        self.g = {k: self.grad[o:o + c].view(shapes[k]) for k, (o, c) in self.offsets.items()}
+        if mean_betas is not None:
+            self.p["betas"].copy_(torch.as_tensor(np.asarray(mean_betas)[:20], **f32))
+        if mean_log_scales is not None and self.ls_shared:
+            self.p["log_beta_scales"].copy_(torch.as_tensor(np.asarray(mean_log_scales), **f32))
+        self.p["global_rotation"].copy_(torch.as_tensor(model_io.initial_global_rotation(), **f32)[None].expand(N, 3))
+        self.global_mask = torch.ones(3, **f32)
+        self.rotation_mask = torch.ones(34, 3, **f32)
+        self.losses = torch.zeros(8, **f32)
+        self.step_count = 0
+        self.halo_prev = self.halo_next = None
+
+    # ---- stage control (optimize_to_joints.py:96-110) --------------------------------------------------
+    def trainable(self, stage_id):
+        if stage_id == 0:
+            return ("global_rotation", "trans")
+        names = ["betas", "joint_rotations", "global_rotation", "trans"]
+        if self.allow_limb_scaling:
+            names.insert(1, "log_beta_scales")
+        return tuple(names)
+
+    def begin_stage(self, stage_id):
+        """fresh optimiser state, as `torch.optim.Adam(model.parameters(), ...)` per stage"""
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.step_count = 0
+        self.stage_id = stage_id
+
+    def _segments(self, names):
+        """contiguous [start, end) runs of the flat buffer covering the trainable tensors"""
+        segs = []
+        for k in PARAM_NAMES:
+            if k not in names:
+                continue
+            o, c = self.offsets[k]
+            if segs and segs[-1][1] == o:
+                segs[-1][1] = o + c
+            else:
+                segs.append([o, o + c])
+        return segs
+
+    # ---- one epoch (optimize_to_joints.py:113-137) ---------------------------------------------------------
+    def evaluate(self, weights, w_temp, stage_id, want=None, **outs):
+        vis = self.visibility_stage0 if stage_id == 0 else self.visibility_full
+        want = self.trainable(stage_id) if want is None else want
+        self.e.fit_eval(betas=self.p["betas"], log_beta_scales=self.p["log_beta_scales"],
+                        global_rotation=self.p["global_rotation"], joint_rotations=self.p["joint_rotations"],
+                        trans=self.p["trans"], target_joints=self.target_joints, target_visibility=vis,
+                        target_sil=self.target_sil, weights=weights, w_temp=w_temp, window=self.window,
+                        temporal=True, global_mask=self.global_mask, rotation_mask=self.rotation_mask,
+                        halo_prev=self.halo_prev, halo_next=self.halo_next,
+                        losses=self.losses, grads=self.g, want=want, **outs)
+        return self.losses
+
+    def apply_adam(self, names, lr):
+        self.step_count += 1
+        for s, t in self._segments(names):
+            eng.adam_step(self.flat[s:t], self.grad[s:t], self.exp_avg[s:t], self.exp_avg_sq[s:t], lr, self.step_count)
+
+    def step(self, weights, w_temp, lr, stage_id):
+        names = self.trainable(stage_id)
+        self.evaluate(weights, w_temp, stage_id, want=names)
+        self.apply_adam(names, lr)
+        return self.losses
+
+    def shared_grad(self):
+        """view of the gradient of the parameters every frame shares (betas, and the limb scales when shared)"""
+        return self.grad[: 20 + (6 if self.ls_shared else 0)]
+
+    def boundary_records(self):
+        """(2,108) masked theta(105)|trans(3) of the first and the last local frame (temporal halo exchange)"""
+        idx = [0, self.N - 1]
+        gr = self.p["global_rotation"][idx] * self.global_mask
+        jr = (self.p["joint_rotations"][idx] * self.rotation_mask).reshape(2, 102)
+        return torch.cat([gr, jr, self.p["trans"][idx]], 1).contiguous()
+
+    def run_schedule(self, opt_weights=None, iters_scale=1.0, on_visualize=None, vis_frequency=None):
+        """The reference's full stage loop. Returns per-stage final loss vectors (host)."""
+        W = np.array(config.OPT_WEIGHTS if opt_weights is None else opt_weights).T
+        vis_frequency = config.VIS_FREQUENCY if vis_frequency is None else vis_frequency
+        history = []
+        for stage_id, w in enumerate(W):
+            weights, w_temp, epochs, lr = w[:6], float(w[6]), max(1, int(round(int(w[7]) * iters_scale))), float(w[8])
+            self.begin_stage(stage_id)
+            for epoch_id in range(epochs):
+                self.step(weights, w_temp, lr, stage_id)
+                if on_visualize is not None and epoch_id % vis_frequency == 0:
+                    on_visualize(self, stage_id, epoch_id)
+            history.append(self.losses.cpu().numpy().copy())
+        return history
+
+    # ---- checkpoints (smal_fitter.py:192-219, optimize_to_joints.py:43-53) -------------------------------------
+    def frame_parameters(self):
+        """list of per-frame dicts with the reference's keys, dtypes and masking"""
+        gr = (self.p["global_rotation"] * self.global_mask).cpu().numpy()
+        jr = (self.p["joint_rotations"] * self.rotation_mask).cpu().numpy()
+        tr = self.p["trans"].cpu().numpy()
+        betas = self.p["betas"].cpu().numpy()
+        ls = self.p["log_beta_scales"].cpu().numpy()
+        out = []
+        for i in range(self.N):
+            out.append({"global_rotation": gr[i].astype(np.float32), "joint_rotations": jr[i].astype(np.float32),
+                        "betas": betas.astype(np.float32),
+                        "log_betascale": (ls if self.ls_shared else ls[i]).astype(np.float32),
+                        "trans": tr[i].astype(np.float32)})
+        return out
+
+    def export_checkpoints(self, output_dirs, stage_id, epoch_name):
+        """writes <dir>/st{stage}_ep{epoch}.pkl per frame, layout of optimize_to_joints.py:46-48"""
+        for d, params in zip(output_dirs, self.frame_parameters()):
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "st{0}_ep{1}.pkl".format(stage_id, epoch_name)), "wb") as f:
+                pickle.dump(params, f)
+
+    def load_checkpoint(self, checkpoint_path, epoch):
+        """reference SMALFitter.load_checkpoint (smal_fitter.py:192-207): per-frame params, betas and scales
+        averaged over frames"""
+        beta_list, scale_list = [], []
+        for frame_id in range(self.N):
+            with open(os.path.join(checkpoint_path, "{0:04}".format(frame_id), "{0}.pkl".format(epoch)), "rb") as f:
+                d = pickle.load(f)
+            dev = self.flat.device
+            self.p["global_rotation"][frame_id] = torch.from_numpy(np.asarray(d["global_rotation"], np.float32)).to(dev)
+            self.p["joint_rotations"][frame_id] = torch.from_numpy(np.asarray(d["joint_rotations"], np.float32)).to(dev).view(34, 3)
+            self.p["trans"][frame_id] = torch.from_numpy(np.asarray(d["trans"], np.float32)).to(dev)
+            beta_list.append(np.asarray(d["betas"])[:topo.NUM_BETAS])
+            scale_list.append(np.asarray(d["log_betascale"]))
+        self.p["betas"].copy_(torch.from_numpy(np.mean(beta_list, axis=0).astype(np.float32)))
+        mean_scale = torch.from_numpy(np.mean(scale_list, axis=0).astype(np.float32)).to(self.flat.device)
+        if self.ls_shared:
+            self.p["log_beta_scales"].copy_(mean_scale)
+        else:
+            self.p["log_beta_scales"].copy_(mean_scale[None].expand(self.N, 6))
