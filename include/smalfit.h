@@ -64,7 +64,7 @@ int smalfit_engine_status(smalfit_engine* engine, void* stream, int* status_bits
  * milliseconds and the number of timed evaluations per section. */
 #define SMALFIT_NUM_SECTIONS 5
 #define SMALFIT_SEC_LBS_FWD 0    /* shape + pose + skin + joints kernels          */
-#define SMALFIT_SEC_RASTER_BIN 1 /* face boxes + raster_sweep_kernel (count, log-alpha) */
+#define SMALFIT_SEC_RASTER_BIN 1 /* face records + raster_sweep_kernel (count, log-alpha) */
 #define SMALFIT_SEC_RASTER_FWD 2 /* raster_resolve_kernel (K-nearest product)     */
 #define SMALFIT_SEC_RASTER_BWD 3 /* raster_bwd_kernel alone                       */
 #define SMALFIT_SEC_LBS_BWD 4    /* vertex / dA / pose-blend / chain adjoints     */

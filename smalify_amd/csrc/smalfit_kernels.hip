@@ -449,54 +449,34 @@ shape_prior_kernel(const float* __restrict__ betas, const float* __restrict__ lo
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5: soft-silhouette rasteriser  (face-parallel sweeps inside pixel windows)
+// K5: soft-silhouette rasteriser
 //
 // pytorch3d keeps, per pixel, only the faces_per_pixel = 100 candidates nearest in depth; with the
 // reference's head-on initial pose a pixel sees hundreds of candidates, so the truncation is first-class.
-// One block owns a 32x32-pixel window of one frame and runs, with LDS-local counters:
-//   count   : every face touching the window sweeps (its blur-expanded pixel box ∩ window) with 16 lanes
-//             in 4x4-pixel patches and counts the pixels it contributes to
-//   scan    : exclusive prefix over the window's 1024 pixels, one global allocation for the window's lists
-//   fill    : same sweep, appends (depth, 1 - p) to the pixel's candidate list in HBM
-//   resolve : thread per pixel: product of (1 - p); pixels with more than K candidates first find the K-th
-//             smallest depth exactly (wave-level 4 x 8-bit radix select on an order-preserving key).
-//             The largest included depth is stored (zthr) so raster_bwd_kernel applies the same truncation.
-// Sweeping a face's own pixel box does ~4.6x fewer lane evaluations than evaluating every face of a tile
-// for all the tile's pixels (measured on the benchmark scenes).
+// Measured on MI355X while designing this (64 frames, 256^2): a frame-wide sweep in which every face walks
+// its own blur-expanded pixel box (16 lanes per face, 4x4-pixel patches) costs 0.17-0.22 ms; evaluating
+// every face of a tile for all the tile's pixels does 4.6x more lane evaluations; one global atomic per
+// candidate is capped at ~50 G/s (memory-side on this multi-XCD part, 0.7 ms per sweep); per-pixel candidate
+// lists in HBM mean 35-50 M scattered 8-byte stores.  Hence:
+//   face_bbox  per-face pixel box + a packed record (box, 3 screen-space vertices), and the union box of every
+//              32 consecutive faces.  Faces are Morton-ordered once at model creation, so consecutive faces are
+//              screen-space neighbours in any pose.
+//   sweep      one block per 128 consecutive faces: candidates are accumulated in a 64x64-pixel LDS window
+//              anchored at the block's union box as ONE packed 64-bit integer per pixel
+//              (count << 50 | sum of -log2(1 - p) in 2^-28 fixed point) and flushed with one global atomic
+//              per touched pixel (10-27x fewer than one per candidate).  Integer adds commute: the result does
+//              not depend on arrival order (deterministic).
+//   resolve    thread per pixel: alpha = 2^-sum.  Pixels with more than K candidates get one wave each: it
+//              walks the 32-face union boxes containing the pixel, evaluates those faces (lane per face),
+//              compacts the candidates into LDS in face order, finds the K-th smallest depth exactly with a
+//              4 x 8-bit radix select on an order-preserving key and multiplies the K nearest (1 - p).
+//              The largest included depth (zthr) is stored so that raster_bwd_kernel truncates identically.
 // ------------------------------------------------------------------------------------------------
-
-// 5a: per-face validity + conservative pixel box of the blur-expanded triangle
-__global__ void __launch_bounds__(256)
-face_bbox_kernel(ModelDev m, int S, const float* __restrict__ proj, int2* __restrict__ fbox) {
-  const int f = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
-  if (f >= m.F) return;
-  const int Vp = m.Vp;
-  const float* px = proj + (size_t)n * 3 * Vp;
-  const int i0 = m.faces[f * 3], i1 = m.faces[f * 3 + 1], i2 = m.faces[f * 3 + 2];
-  FaceRec r;
-  const bool ok = make_face_rec(px[i0], px[Vp + i0], px[2 * Vp + i0], px[i1], px[Vp + i1], px[2 * Vp + i1],
-                                px[i2], px[Vp + i2], px[2 * Vp + i2], r);
-  int2 box = make_int2(1, 1);     // c0=1 > c1=0 : empty
-  if (ok) {
-    const float xlo = fminf(px[i0], fminf(px[i1], px[i2])) - kBlurSqrt;
-    const float xhi = fmaxf(px[i0], fmaxf(px[i1], px[i2])) + kBlurSqrt;
-    const float ylo = fminf(px[Vp + i0], fminf(px[Vp + i1], px[Vp + i2])) - kBlurSqrt;
-    const float yhi = fmaxf(px[Vp + i0], fmaxf(px[Vp + i1], px[Vp + i2])) + kBlurSqrt;
-    // pixel centre x_p = 1 - (2c+1)/S  =>  c = ((1 - x_p) S - 1) / 2 ; one pixel of slack either side
-    const float fs = (float)S;
-    float c0 = floorf(((1.0f - xhi) * fs - 1.0f) * 0.5f) - 1.0f;
-    float c1 = ceilf(((1.0f - xlo) * fs - 1.0f) * 0.5f) + 1.0f;
-    float r0 = floorf(((1.0f - yhi) * fs - 1.0f) * 0.5f) - 1.0f;
-    float r1 = ceilf(((1.0f - ylo) * fs - 1.0f) * 0.5f) + 1.0f;
-    c0 = fminf(fmaxf(c0, 0.f), fs - 1.f); c1 = fminf(fmaxf(c1, -1.f), fs - 1.f);
-    r0 = fminf(fmaxf(r0, 0.f), fs - 1.f); r1 = fminf(fmaxf(r1, -1.f), fs - 1.f);
-    const bool finite = (xlo == xlo) && (xhi == xhi) && (ylo == ylo) && (yhi == yhi);
-    const bool onscreen = finite && (xhi >= -1.0f) && (xlo <= 1.0f) && (yhi >= -1.0f) && (ylo <= 1.0f) &&
-                          (c1 >= c0) && (r1 >= r0);
-    if (onscreen) box = make_int2((int)c0 | ((int)c1 << 16), (int)r0 | ((int)r1 << 16));
-  }
-  fbox[(size_t)n * m.F + f] = box;
-}
+constexpr int kRectFaces = 8;             // faces per entry of the union-box index
+constexpr int kSweepFaces = 128;          // faces per sweep block
+constexpr int kAccWin = 64;               // LDS accumulator window edge (pixels)
+constexpr int kCountShift = 50;
+constexpr float kLogFix = 268435456.0f;   // 2^28
 
 __device__ __forceinline__ unsigned orderable(float f) {
   const unsigned u = __float_as_uint(f);
@@ -510,184 +490,254 @@ __device__ __forceinline__ float wave_prod(float v) {
   for (int o = 32; o > 0; o >>= 1) v *= __shfl_xor(v, o, 64);
   return v;
 }
-__device__ __forceinline__ bool box_overlaps(int2 b, int x0, int x1, int y0, int y1) {
-  const int c0 = b.x & 0xffff, c1 = b.x >> 16, r0 = b.y & 0xffff, r1 = b.y >> 16;
-  return (c0 <= c1) && (c0 <= x1) && (c1 >= x0) && (r0 <= y1) && (r1 >= y0);
+__device__ __forceinline__ bool box_contains(int2 b, int x, int y) {
+  return (b.x & 0xffff) <= x && x <= (b.x >> 16) && (b.y & 0xffff) <= y && y <= (b.y >> 16);
+}
+__device__ __forceinline__ unsigned long long pack_candidate(float d) {
+  return (1ull << kCountShift) | (unsigned long long)(-log2_one_minus_prob(d) * kLogFix);
 }
 
-// 5b: sweep.  One 256-thread block per (32x32-pixel window, face group, frame).  No candidate lists are
-// materialised (35-50 M scattered 8-byte stores per iteration made list-building DRAM-bound): per pixel the
-// block keeps, in LDS, the candidate count and the sum of log2(1 - p) in 2^-40 fixed point.  Integer adds
-// commute, so the result is independent of the order in which faces arrive (deterministic), and the
-// logarithm is formed from d directly (logsigmoid), which is at least as accurate as multiplying
-// rounded (1 - p) factors.  Hot windows of a small / head-on object are split over kFaceGroups blocks.
-constexpr int kWin = 32;
-constexpr int kWinPix = kWin * kWin;
-constexpr int kFaceGroups = 8;
-constexpr int kGroupCap = 1024;          // faces per group (F <= kFaceGroups * kGroupCap)
-constexpr double kFix = 1099511627776.0; // 2^40
-
+// 5a: per-face validity, conservative pixel box, packed record; union box per 32 faces
 __global__ void __launch_bounds__(256)
-raster_sweep_kernel(ModelDev m, int S, const float* __restrict__ proj, const int2* __restrict__ fbox,
-                    int* __restrict__ part_cnt /*[M][NW][G][1024]*/, long long* __restrict__ part_ls,
-                    int* __restrict__ wcount /*[M][NW][G]*/, int* __restrict__ wlist /*[M][NW][G][kGroupCap]*/, int dbg) {
-  __shared__ int cnt[kWinPix];
-  __shared__ unsigned long long lsum[kWinPix];
-  __shared__ int wl[kGroupCap];
-  __shared__ int wave_cnt[4];
-  const int n = blockIdx.z, g = blockIdx.y, wdw = blockIdx.x;
-  const int WX = (S + kWin - 1) / kWin;
-  const int X0 = (wdw % WX) * kWin, Y0 = (wdw / WX) * kWin;
-  const int X1 = min(X0 + kWin - 1, S - 1), Y1 = min(Y0 + kWin - 1, S - 1);
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int F = m.F, Vp = m.Vp;
-  const int per = (F + kFaceGroups - 1) / kFaceGroups;
-  const int f_lo = g * per, f_hi = min(F, f_lo + per);
-  const int2* fb = fbox + (size_t)n * F;
-  const size_t blk = ((size_t)n * gridDim.x + wdw) * kFaceGroups + g;
-  for (int i = t; i < kWinPix; i += 256) { cnt[i] = 0; lsum[i] = 0ull; }
-  // ---- faces of this group whose pixel box touches the window (stable order) ---------------------------------
-  int nw = 0;
-  for (int fbase = f_lo; fbase < f_hi; fbase += 256) {
-    const int f = fbase + t;
-    const bool hit = (f < f_hi) && box_overlaps(fb[f], X0, X1, Y0, Y1);
-    const unsigned long long bal = __ballot(hit);
-    __syncthreads();
-    if (lane == 0) wave_cnt[w] = __popcll(bal);
-    __syncthreads();
-    int woff = 0, total = 0;
+face_bbox_kernel(ModelDev m, int S, const float* __restrict__ proj, int2* __restrict__ fbox,
+                 float4* __restrict__ frec /*[M][F][3]*/, int4* __restrict__ brect /*[M][ceil(F/32)]*/) {
+  const int f = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  const int Vp = m.Vp;
+  const float* px = proj + (size_t)n * 3 * Vp;
+  int2 box = make_int2(1, 1);     // c0=1 > c1=0 : empty
+  if (f < m.F) {
+    const int i0 = m.faces[f * 3], i1 = m.faces[f * 3 + 1], i2 = m.faces[f * 3 + 2];
+    const float ax = px[i0], ay = px[Vp + i0], az = px[2 * Vp + i0];
+    const float bx = px[i1], by = px[Vp + i1], bz = px[2 * Vp + i1];
+    const float cx = px[i2], cy = px[Vp + i2], cz = px[2 * Vp + i2];
+    FaceRec r;
+    const bool ok = make_face_rec(ax, ay, az, bx, by, bz, cx, cy, cz, r);
+    if (ok) {
+      const float xlo = fminf(ax, fminf(bx, cx)) - kBlurSqrt, xhi = fmaxf(ax, fmaxf(bx, cx)) + kBlurSqrt;
+      const float ylo = fminf(ay, fminf(by, cy)) - kBlurSqrt, yhi = fmaxf(ay, fmaxf(by, cy)) + kBlurSqrt;
+      // pixel centre x_p = 1 - (2c+1)/S  =>  c = ((1 - x_p) S - 1) / 2 ; one pixel of slack either side
+      const float fs = (float)S;
+      float c0 = floorf(((1.0f - xhi) * fs - 1.0f) * 0.5f) - 1.0f;
+      float c1 = ceilf(((1.0f - xlo) * fs - 1.0f) * 0.5f) + 1.0f;
+      float r0 = floorf(((1.0f - yhi) * fs - 1.0f) * 0.5f) - 1.0f;
+      float r1 = ceilf(((1.0f - ylo) * fs - 1.0f) * 0.5f) + 1.0f;
+      c0 = fminf(fmaxf(c0, 0.f), fs - 1.f); c1 = fminf(fmaxf(c1, -1.f), fs - 1.f);
+      r0 = fminf(fmaxf(r0, 0.f), fs - 1.f); r1 = fminf(fmaxf(r1, -1.f), fs - 1.f);
+      const bool finite = (xlo == xlo) && (xhi == xhi) && (ylo == ylo) && (yhi == yhi);
+      const bool onscreen = finite && (xhi >= -1.0f) && (xlo <= 1.0f) && (yhi >= -1.0f) && (ylo <= 1.0f) &&
+                            (c1 >= c0) && (r1 >= r0);
+      if (onscreen) box = make_int2((int)c0 | ((int)c1 << 16), (int)r0 | ((int)r1 << 16));
+    }
+    fbox[(size_t)n * m.F + f] = box;
+    float4* o = frec + ((size_t)n * m.F + f) * 3;
+    o[0] = make_float4(__int_as_float(box.x), __int_as_float(box.y), ax, ay);
+    o[1] = make_float4(az, bx, by, bz);
+    o[2] = make_float4(cx, cy, cz, 0.f);
+  }
+  // union box of each group of kRectFaces consecutive faces (sub-wave shuffle reduction)
+  const bool live = (box.x & 0xffff) <= (box.x >> 16);
+  int x0 = live ? (box.x & 0xffff) : 0x7fff, x1 = live ? (box.x >> 16) : -1;
+  int y0 = live ? (box.y & 0xffff) : 0x7fff, y1 = live ? (box.y >> 16) : -1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { if (i < w) woff += wave_cnt[i]; total += wave_cnt[i]; }
-    if (hit) wl[nw + woff + __popcll(bal & ((1ull << lane) - 1ull))] = f;
-    nw += total;
+  for (int o = kRectFaces / 2; o > 0; o >>= 1) {
+    x0 = min(x0, __shfl_xor(x0, o, kRectFaces)); x1 = max(x1, __shfl_xor(x1, o, kRectFaces));
+    y0 = min(y0, __shfl_xor(y0, o, kRectFaces)); y1 = max(y1, __shfl_xor(y1, o, kRectFaces));
+  }
+  if ((threadIdx.x & (kRectFaces - 1)) == 0 && f < m.F)
+    brect[(size_t)n * ((m.F + kRectFaces - 1) / kRectFaces) + f / kRectFaces] = make_int4(x0, x1, y0, y1);
+}
+
+__device__ __forceinline__ bool load_face_rec(const float4* __restrict__ fr, FaceRec& r, int2& box) {
+  const float4 a = fr[0], b = fr[1], c = fr[2];
+  box = make_int2(__float_as_int(a.x), __float_as_int(a.y));
+  return make_face_rec(a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, r);
+}
+
+// 5b: sweep
+__global__ void __launch_bounds__(256)
+raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, unsigned long long* __restrict__ gacc /*[M][S*S]*/) {
+  __shared__ __attribute__((aligned(16))) FaceRec recs[kSweepFaces];
+  __shared__ int2 boxes[kSweepFaces];
+  __shared__ unsigned long long acc[kAccWin * kAccWin];
+  __shared__ int rect[4];
+  const int n = blockIdx.y, t = threadIdx.x;
+  const int f0 = blockIdx.x * kSweepFaces;
+  if (t < 4) rect[t] = (t & 1) ? -1 : 0x7fff;          // x0, x1, y0, y1
+  for (int i = t; i < kAccWin * kAccWin; i += 256) acc[i] = 0ull;
+  __syncthreads();
+  if (t < kSweepFaces) {
+    int2 box = make_int2(1, 1);
+    if (f0 + t < F) {
+      FaceRec r;
+      load_face_rec(frec + ((size_t)n * F + f0 + t) * 3, r, box);
+      recs[t] = r;
+    }
+    boxes[t] = box;
+    if ((box.x & 0xffff) <= (box.x >> 16)) {
+      atomicMin(&rect[0], box.x & 0xffff); atomicMax(&rect[1], box.x >> 16);
+      atomicMin(&rect[2], box.y & 0xffff); atomicMax(&rect[3], box.y >> 16);
+    }
   }
   __syncthreads();
-  if (t == 0) wcount[blk] = nw;
-  if (nw == 0 || (dbg & 8)) return;
-  for (int i = t; i < nw; i += 256) wlist[blk * kGroupCap + i] = wl[i];
-  // ---- evaluation sweep: 16 lanes per face walk (box ∩ window) in 4x4 patches -----------------------------------
+  if (rect[1] < rect[0]) return;                        // no face of this block is on screen
+  const int wx0 = rect[0], wy0 = rect[2];
+  unsigned long long* ga = gacc + (size_t)n * S * S;
   const int sub = t & 15, lx = sub & 3, ly = sub >> 2, grp = t >> 4;
-  const float* pv = proj + (size_t)n * 3 * Vp;
   const float inv_s = 1.0f / (float)S;
-  for (int g0 = 0; g0 < nw; g0 += 16) {
-    const int gi = g0 + grp;
-    if (gi < nw) {
-      const int ff = wl[gi];
-      const int2 box = fb[ff];
-      const int c0 = max(box.x & 0xffff, X0), c1 = min(box.x >> 16, X1);
-      const int r0 = max(box.y & 0xffff, Y0), r1 = min(box.y >> 16, Y1);
-      const int i0 = m.faces[ff * 3], i1 = m.faces[ff * 3 + 1], i2 = m.faces[ff * 3 + 2];
-      FaceRec r;
-      make_face_rec(pv[i0], pv[Vp + i0], pv[2 * Vp + i0], pv[i1], pv[Vp + i1], pv[2 * Vp + i1],
-                    pv[i2], pv[Vp + i2], pv[2 * Vp + i2], r);
-      for (int ry = r0; ry <= r1; ry += 4) {
-        const int row = ry + ly;
-        for (int cx = c0; cx <= c1; cx += 4) {
-          const int col = cx + lx;
-          if (row > r1 || col > c1) continue;
-          PixEval e;
-          if (dbg & 4) { if (col == 100000) cnt[0] = 1; continue; }
-          if (!face_pixel_eval(r, pix_to_ndc(col, inv_s), pix_to_ndc(row, inv_s), e)) continue;
-          const int pl = (row - Y0) * kWin + (col - X0);
-          if (dbg & 1) { if (e.d == 12345.f) cnt[pl] = 1; continue; }
-          atomicAdd(&cnt[pl], 1);
-          if (dbg & 2) { if (e.d == 12345.f) cnt[pl] = 1; continue; }
-          const long long fx = (long long)((double)log2_one_minus_prob(e.d) * kFix);
-          atomicAdd(&lsum[pl], (unsigned long long)fx);
-        }
+  for (int step = 0; step < kSweepFaces / 16; ++step) {
+    const int k = step * 16 + grp;
+    const int2 box = boxes[k];
+    const int c0 = box.x & 0xffff, c1 = box.x >> 16, r0 = box.y & 0xffff, r1 = box.y >> 16;
+    if (c0 > c1) continue;
+    for (int ry = r0; ry <= r1; ry += 4) {
+      const int row = ry + ly;
+      for (int cx = c0; cx <= c1; cx += 4) {
+        const int col = cx + lx;
+        if (row > r1 || col > c1) continue;
+        PixEval e;
+        if (!face_pixel_eval(recs[k], pix_to_ndc(col, inv_s), pix_to_ndc(row, inv_s), e)) continue;
+        const unsigned long long v = pack_candidate(e.d);
+        const int lxw = col - wx0, lyw = row - wy0;
+        if (lxw < kAccWin && lyw < kAccWin) atomicAdd(&acc[lyw * kAccWin + lxw], v);
+        else atomicAdd(&ga[row * S + col], v);
       }
     }
   }
   __syncthreads();
-  for (int i = t; i < kWinPix; i += 256) {
-    part_cnt[blk * kWinPix + i] = cnt[i];
-    part_ls[blk * kWinPix + i] = (long long)lsum[i];
+  const int ww = min(kAccWin, rect[1] - wx0 + 1), wh = min(kAccWin, rect[3] - wy0 + 1);
+  for (int i = t; i < wh * kAccWin; i += 256) {
+    const int lyw = i / kAccWin, lxw = i % kAccWin;
+    if (lxw >= ww) continue;
+    const unsigned long long v = acc[lyw * kAccWin + lxw];
+    if (v) atomicAdd(&ga[(wy0 + lyw) * S + wx0 + lxw], v);
   }
 }
 
-// 5c: resolve.  One 256-thread block per 16x16-pixel tile (thread per pixel): alpha = 2^(sum of the group
-// partial log sums).  Pixels with more than K candidates are queued and handled one per wave: the lanes
-// split the window's face lists, evaluate the faces covering the pixel and compact the candidates into
-// LDS in list order; the K-th smallest depth is found exactly by a 4 x 8-bit radix select on an
-// order-preserving key and the K nearest (1 - p) are multiplied in a fixed order.
-constexpr int kCandCap = 1024;            // candidates per pixel kept in LDS; beyond: multi-pass re-evaluation
-
+// 5c: resolve.  Thread per pixel: alpha = 2^-sum.  Pixels with more than K candidates are appended to a
+// global queue (one atomic per block) and finished by raster_select_kernel.
 __global__ void __launch_bounds__(256)
-raster_resolve_kernel(ModelDev m, int S, int M, int window, float w_sil, const float* __restrict__ proj,
-                      const int2* __restrict__ fbox, const int* __restrict__ part_cnt,
-                      const long long* __restrict__ part_ls, const int* __restrict__ wcount,
-                      const int* __restrict__ wlist, const float* __restrict__ tsil,
-                      float* __restrict__ sil_out, float2* __restrict__ gz, float* __restrict__ blk_loss) {
-  __shared__ unsigned hist[4][256];
-  __shared__ float2 cand[4][kCandCap];
-  __shared__ int queue[256];
-  __shared__ float q_alpha[256], q_zthr[256];
-  __shared__ int qn;
+raster_resolve_kernel(int S, int M, int window, float w_sil, const unsigned long long* __restrict__ gacc,
+                      const float* __restrict__ tsil, float* __restrict__ sil_out, float2* __restrict__ gz,
+                      float* __restrict__ blk_loss, int* __restrict__ qcount, int* __restrict__ queue) {
+  __shared__ int qn, qbase;
   __shared__ float red[16];
-  constexpr int K = kFacesPerPixel;
-  constexpr int RC = kCandCap / 64;
   const int n = blockIdx.y;
-  const int TX = (S + 15) / 16, WX = (S + kWin - 1) / kWin;
+  const int TX = (S + 15) / 16;
   const int tx = blockIdx.x % TX, ty = blockIdx.x / TX;
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int t = threadIdx.x;
   const int col = tx * 16 + (t & 15), row = ty * 16 + (t >> 4);
   const bool inimg = (col < S) && (row < S);
-  const int wdw = (ty / 2) * WX + (tx / 2);
-  const int pl = ((ty & 1) * 16 + (t >> 4)) * kWin + (tx & 1) * 16 + (t & 15);
-  const float INF = __int_as_float(0x7f800000);
-  const int NW = WX * ((S + kWin - 1) / kWin);
-  const size_t blk0 = ((size_t)n * NW + wdw) * kFaceGroups;
   if (t == 0) qn = 0;
+  __syncthreads();
   int c = 0;
-  long long ls = 0;
-#pragma unroll
-  for (int g = 0; g < kFaceGroups; ++g) {
-    if (wcount[blk0 + g] > 0 && inimg) {        // block-uniform group test
-      c += part_cnt[(blk0 + g) * kWinPix + pl];
-      ls += part_ls[(blk0 + g) * kWinPix + pl];
-    }
+  float alpha = 1.0f;
+  if (inimg) {
+    const unsigned long long v = gacc[((size_t)n * S + row) * S + col];
+    c = (int)(v >> kCountShift);
+    if (c > 0 && c <= kFacesPerPixel)
+      alpha = (float)exp2(-(double)(v & ((1ull << kCountShift) - 1ull)) * (1.0 / (double)kLogFix));
   }
+  const bool queued = c > kFacesPerPixel;
+  int slot = 0;
+  if (queued) slot = atomicAdd(&qn, 1);
   __syncthreads();
-  float alpha = (c > 0) ? (float)exp2((double)ls * (1.0 / kFix)) : 1.0f;
-  float zthr = INF;
-  const bool queued = c > K;
-  if (queued) queue[atomicAdd(&qn, 1)] = t;
+  if (t == 0) qbase = qn > 0 ? atomicAdd(qcount, qn) : 0;
   __syncthreads();
-  const int nqueued = qn;
-  const int Vp = m.Vp;
-  const float* pv = proj + (size_t)n * 3 * Vp;
-  const int2* fb = fbox + (size_t)n * m.F;
+  if (queued) queue[qbase + slot] = (n * S + row) * S + col;
+  float l = 0.f;
+  if (inimg && !queued) {
+    const size_t pi = ((size_t)n * S + row) * S + col;
+    const float sil = 1.0f - alpha;
+    if (sil_out) sil_out[pi] = sil;
+    float gx = 0.f;
+    if (tsil) {
+      const float diff = sil - tsil[pi];
+      l = fabsf(diff);
+      const int Bn = frame_window_size(n, M, window);
+      const float sgn = (diff > 0.f) ? 1.0f : ((diff < 0.f) ? -1.0f : 0.0f);
+      gx = -(w_sil / ((float)Bn * (float)S * (float)S)) * sgn * alpha * (1.0f / kSigma);
+    }
+    if (gz) gz[pi] = make_float2(gx, __int_as_float(0x7f800000));
+  }
+  if (blk_loss) {
+    l = block_sum(l, red);
+    if (t == 0) blk_loss[(size_t)n * gridDim.x + blockIdx.x] = l;
+  }
+}
+
+// 5d: select.  Persistent grid; one wave per queued pixel: it walks the union boxes (8 faces each)
+// containing the pixel, evaluates those faces (lane per face), compacts the candidates into LDS in face
+// order, finds the K-th smallest depth exactly (4 x 8-bit radix select on an order-preserving key) and
+// multiplies the K nearest (1 - p) in a fixed order.
+constexpr int kCandCap = 1024;            // candidates per pixel kept in LDS; beyond: multi-pass re-evaluation
+constexpr int kHitCap = 1024;             // union boxes containing a pixel kept in LDS
+
+__global__ void __launch_bounds__(256)
+raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4* __restrict__ frec,
+                     const int4* __restrict__ brect, const int* __restrict__ qcount, const int* __restrict__ queue,
+                     const float* __restrict__ tsil, float* __restrict__ sil_out, float2* __restrict__ gz,
+                     float* __restrict__ qloss /*[queue length]: weighted |sil - target| or null*/) {
+  __shared__ unsigned hist[4][256];
+  __shared__ float2 cand[4][kCandCap];
+  __shared__ int hits[4][kHitCap];
+  constexpr int K = kFacesPerPixel;
+  constexpr int RC = kCandCap / 64;
+  constexpr int RPI = 64 / kRectFaces;      // union boxes handled per wave iteration
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int nq = *qcount;
+  const int nrect = (F + kRectFaces - 1) / kRectFaces;
   const float inv_s = 1.0f / (float)S;
-  for (int qi = w; qi < nqueued; qi += 4) {
-    const int src = queue[qi];
-    const int pcol = tx * 16 + (src & 15), prow = ty * 16 + (src >> 4);
+  const int npix = S * S;
+  for (int qi = blockIdx.x * 4 + w; qi < nq; qi += gridDim.x * 4) {
+    const int gp = queue[qi];
+    const int n = gp / npix, pix = gp % npix;
+    const int pcol = pix % S, prow = pix / S;
     const float ppx = pix_to_ndc(pcol, inv_s), ppy = pix_to_ndc(prow, inv_s);
-    // visit every candidate of the pixel in list order: fn(valid, pz, one_minus_p) is called wave-wide
+    const int4* br = brect + (size_t)n * nrect;
+    const float4* fr = frec + (size_t)n * F * 3;
+    // union boxes containing the pixel (ascending)
+    int nh = 0;
+    for (int r0 = 0; r0 < nrect; r0 += 64) {
+      const int ri = r0 + lane;
+      bool hit = false;
+      if (ri < nrect) { const int4 b = br[ri]; hit = b.x <= pcol && pcol <= b.y && b.z <= prow && prow <= b.w; }
+      const unsigned long long bal = __ballot(hit);
+      if (hit) { const int pos = nh + __popcll(bal & ((1ull << lane) - 1ull)); if (pos < kHitCap) hits[w][pos] = ri; }
+      nh += __popcll(bal);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // visit every candidate of the pixel in face order: fn(valid, pz, d) is called wave-wide
     auto scan_candidates = [&](auto&& fn) {
-      for (int g = 0; g < kFaceGroups; ++g) {
-        const int nwg = wcount[blk0 + g];
-        const int* list = wlist + (blk0 + g) * kGroupCap;
-        for (int i0 = 0; i0 < nwg; i0 += 64) {
-          const int i = i0 + lane;
+      if (nh <= kHitCap) {
+        for (int j = 0; j < nh; j += RPI) {
+          const int hj = j + lane / kRectFaces;
           bool ok = false;
-          PixEval e;
-          e.pz = 0.f; e.d = 0.f;
-          if (i < nwg) {
-            const int ff = list[i];
-            const int2 box = fb[ff];
-            if ((box.x & 0xffff) <= pcol && pcol <= (box.x >> 16) && (box.y & 0xffff) <= prow && prow <= (box.y >> 16)) {
-              const int i0v = m.faces[ff * 3], i1v = m.faces[ff * 3 + 1], i2v = m.faces[ff * 3 + 2];
-              FaceRec r;
-              make_face_rec(pv[i0v], pv[Vp + i0v], pv[2 * Vp + i0v], pv[i1v], pv[Vp + i1v], pv[2 * Vp + i1v],
-                            pv[i2v], pv[Vp + i2v], pv[2 * Vp + i2v], r);
-              ok = face_pixel_eval(r, ppx, ppy, e);
+          PixEval e; e.pz = 0.f; e.d = 0.f;
+          if (hj < nh) {
+            const int ff = hits[w][hj] * kRectFaces + (lane & (kRectFaces - 1));
+            if (ff < F) {
+              FaceRec r; int2 box;
+              load_face_rec(fr + (size_t)ff * 3, r, box);
+              if (box_contains(box, pcol, prow)) ok = face_pixel_eval(r, ppx, ppy, e);
             }
+          }
+          fn(ok, e.pz, e.d);
+        }
+      } else {                      // pathological: walk every face
+        for (int f0 = 0; f0 < F; f0 += 64) {
+          const int ff = f0 + lane;
+          bool ok = false;
+          PixEval e; e.pz = 0.f; e.d = 0.f;
+          if (ff < F) {
+            FaceRec r; int2 box;
+            load_face_rec(fr + (size_t)ff * 3, r, box);
+            if (box_contains(box, pcol, prow)) ok = face_pixel_eval(r, ppx, ppy, e);
           }
           fn(ok, e.pz, e.d);
         }
       }
     };
-    // pass A: compact candidates into LDS (list order)
     int nc = 0;
     scan_candidates([&](bool ok, float pz, float d) {
       const unsigned long long bal = __ballot(ok);
@@ -772,28 +822,23 @@ raster_resolve_kernel(ModelDev m, int S, int M, int window, float w_sil, const f
       scan_candidates([&](bool ok, float pz, float d) { if (ok && orderable(pz) <= prefix) a *= one_minus_prob(d); });
     }
     a = wave_prod(a);
-    if (lane == 0) { q_alpha[src] = a; q_zthr[src] = from_orderable(prefix); }
-  }
-  __syncthreads();
-  if (queued) { alpha = q_alpha[t]; zthr = q_zthr[t]; }
-  float l = 0.f;
-  if (inimg) {
-    const size_t pi = ((size_t)n * S + row) * S + col;
-    const float sil = 1.0f - alpha;
-    if (sil_out) sil_out[pi] = sil;
-    float gx = 0.f;
-    if (tsil) {
-      const float diff = sil - tsil[pi];
-      l = fabsf(diff);
-      const int Bn = frame_window_size(n, M, window);
-      const float sgn = (diff > 0.f) ? 1.0f : ((diff < 0.f) ? -1.0f : 0.0f);
-      gx = -(w_sil / ((float)Bn * (float)S * (float)S)) * sgn * alpha * (1.0f / kSigma);
+    if (lane == 0) {
+      const size_t pi = (size_t)gp;
+      const float sil = 1.0f - a;
+      if (sil_out) sil_out[pi] = sil;
+      float gx = 0.f, l = 0.f;
+      if (tsil) {
+        const float diff = sil - tsil[pi];
+        const int Bn = frame_window_size(n, M, window);
+        const float wn = w_sil / ((float)Bn * (float)S * (float)S);
+        l = fabsf(diff) * wn;
+        const float sgn = (diff > 0.f) ? 1.0f : ((diff < 0.f) ? -1.0f : 0.0f);
+        gx = -wn * sgn * a * (1.0f / kSigma);
+      }
+      if (gz) gz[pi] = make_float2(gx, from_orderable(prefix));
+      if (qloss) qloss[qi] = l;
     }
-    if (gz) gz[pi] = make_float2(gx, zthr);
-  }
-  if (blk_loss) {
-    l = block_sum(l, red);
-    if (t == 0) blk_loss[(size_t)n * gridDim.x + blockIdx.x] = l;
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -1219,6 +1264,10 @@ assemble_kernel(AssembleArgs a) {
         const int Bn = frame_window_size(n, M, a.window);
         lsil += a.tile_loss[k] * (a.w_sil / ((float)Bn * (float)a.S * (float)a.S));
       }
+    }
+    if (a.qloss && a.qcount) {
+      const int nq = *a.qcount;
+      for (int k = t; k < nq; k += 256) lsil += a.qloss[k];
     }
     lsil = block_sum(lsil, red);
     if (t < 8) {
