@@ -147,6 +147,21 @@ typedef struct smalfit_fit_args {
 
 int smalfit_fit_eval(smalfit_engine* engine, void* stream, const smalfit_fit_args* args);
 
+/* ---- Prior.__call__ ---------------------------------------------------------------------------------
+ * replaces: Prior.__call__(x)                                 reference smal_fitter/priors/pose_prior_35.py:112-124
+ * x (N,105) -> out (N,105) = (((x - mean) prec) * mask)^2 with the prior given to set_pose_prior */
+int smalfit_pose_prior(smalfit_engine* engine, void* stream, int N, const float* x, float* out);
+int smalfit_pose_prior_backward(smalfit_engine* engine, void* stream, int N, const float* x, const float* dout,
+                                float* dx);
+
+/* ---- SMALFitter.get_temporal ----------------------------------------------------------------------------
+ * replaces: SMALFitter.get_temporal(w_temp) and its backward    reference smal_fitter/smal_fitter.py:177-190
+ * losses (3,) = joint, global, trans; gradients wrt the raw (unmasked) parameters; any g_* may be NULL */
+int smalfit_temporal(smalfit_engine* engine, void* stream, int N, float w_temp, const float* global_rotation,
+                     const float* joint_rotations, const float* trans, const float* global_mask,
+                     const float* rotation_mask, float* losses, float* g_global_rotation,
+                     float* g_joint_rotations, float* g_trans);
+
 /* ---- torch.optim.Adam.step -----------------------------------------------------------------------
  * replaces: torch.optim.Adam(lr, betas=(0.5, 0.999)).step()  reference smal_fitter/optimize_to_joints.py:96,137
  * t = 1-based step count; eps outside the bias-corrected sqrt, as torch does */

@@ -65,6 +65,9 @@ SIGNATURES = {
     "smalfit_render_backward": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP]),
     "smalfit_project_points_backward": (_I, [_VP, _I, _I, _VP, _VP, _VP]),
     "smalfit_fit_eval": (_I, [_VP, _VP, C.POINTER(FitArgs)]),
+    "smalfit_pose_prior": (_I, [_VP, _VP, _I, _VP, _VP]),
+    "smalfit_pose_prior_backward": (_I, [_VP, _VP, _I, _VP, _VP, _VP]),
+    "smalfit_temporal": (_I, [_VP, _VP, _I, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "smalfit_adam_step": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _F, _F, _F, _F, _I]),
 }
 

@@ -1381,6 +1381,42 @@ __global__ void rodrigues_bwd_kernel(int count, const float* __restrict__ th, co
   dth[i * 3] = d[0]; dth[i * 3 + 1] = d[1]; dth[i * 3 + 2] = d[2];
 }
 
+// Prior.__call__ on its own (pose_prior_35.py:117-124): out[n][c] = (((x - mu) P)[c] * mask[c])^2
+__global__ void __launch_bounds__(128)
+pose_prior_kernel(const float* __restrict__ x, const float* __restrict__ prec, const float* __restrict__ mean,
+                  const float* __restrict__ mask, float* __restrict__ out /*[N][105]*/) {
+  __shared__ float xs[105];
+  const int n = blockIdx.x, t = threadIdx.x;
+  if (t < 105) xs[t] = x[n * 105 + t] - mean[t];
+  __syncthreads();
+  if (t < 105) {
+    float acc = 0.f;
+    for (int r = 0; r < 105; ++r) acc = fmaf(xs[r], prec[r * 105 + t], acc);
+    acc *= mask[t];
+    out[n * 105 + t] = acc * acc;
+  }
+}
+// adjoint: dx[n][r] = sum_c dout[n][c] * 2 res[c] mask[c] P[r][c]
+__global__ void __launch_bounds__(128)
+pose_prior_bwd_kernel(const float* __restrict__ x, const float* __restrict__ prec, const float* __restrict__ mean,
+                      const float* __restrict__ mask, const float* __restrict__ dout, float* __restrict__ dx) {
+  __shared__ float xs[105], g[105];
+  const int n = blockIdx.x, t = threadIdx.x;
+  if (t < 105) xs[t] = x[n * 105 + t] - mean[t];
+  __syncthreads();
+  if (t < 105) {
+    float acc = 0.f;
+    for (int r = 0; r < 105; ++r) acc = fmaf(xs[r], prec[r * 105 + t], acc);
+    g[t] = 2.0f * acc * mask[t] * mask[t] * dout[n * 105 + t];
+  }
+  __syncthreads();
+  if (t < 105) {
+    float acc = 0.f;
+    for (int c = 0; c < 105; ++c) acc = fmaf(g[c], prec[t * 105 + c], acc);
+    dx[n * 105 + t] = acc;
+  }
+}
+
 __global__ void zero_int_kernel(int count, int* p) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) p[i] = 0;

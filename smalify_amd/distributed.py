@@ -46,12 +46,13 @@ class ShardedFitter:
 
     def exchange_halos(self):
         f = self.fitter
-        rec = f.boundary_records()                      # (2,108)
-        if self._gather is None or self._gather.shape[0] != self.world:
-            self._gather = torch.empty(self.world, 2, 108, device=rec.device, dtype=rec.dtype)
+        rec = f.boundary_records().reshape(-1)          # (2*108,)
+        if self._gather is None or self._gather.numel() != self.world * 216:
+            self._gather = torch.empty(self.world * 216, device=rec.device, dtype=rec.dtype)
         dist.all_gather_into_tensor(self._gather, rec, group=self.group)
-        f.halo_prev = self._gather[self.rank - 1, 1].contiguous() if self.rank > 0 else None
-        f.halo_next = self._gather[self.rank + 1, 0].contiguous() if self.rank + 1 < self.world else None
+        g = self._gather.view(self.world, 2, 108)
+        f.halo_prev = g[self.rank - 1, 1].contiguous() if self.rank > 0 else None
+        f.halo_next = g[self.rank + 1, 0].contiguous() if self.rank + 1 < self.world else None
 
     def step(self, weights, w_temp, lr, stage_id):
         f = self.fitter

@@ -222,6 +222,32 @@ class Engine:
         return dpoints
 
 
+def pose_prior(engine, x):
+    N = int(x.shape[0])
+    out = torch.empty(N, 105, device=x.device)
+    check(engine.lib.smalfit_pose_prior(engine.handle, _stream(), N, _ptr(x), _ptr(out)), "smalfit_pose_prior")
+    return out
+
+
+def pose_prior_backward(engine, x, dout):
+    N = int(x.shape[0])
+    dx = torch.empty(N, 105, device=x.device)
+    check(engine.lib.smalfit_pose_prior_backward(engine.handle, _stream(), N, _ptr(x), _ptr(dout), _ptr(dx)),
+          "smalfit_pose_prior_backward")
+    return dx
+
+
+def temporal(engine, w_temp, global_rotation, joint_rotations, trans, global_mask=None, rotation_mask=None):
+    """-> (losses (3,) joint/global/trans, g_global_rotation, g_joint_rotations, g_trans)"""
+    N = int(global_rotation.shape[0])
+    losses = torch.empty(3, device=trans.device)
+    gg, gj, gt = torch.empty_like(global_rotation), torch.empty_like(joint_rotations), torch.empty_like(trans)
+    check(engine.lib.smalfit_temporal(engine.handle, _stream(), N, float(w_temp), _ptr(global_rotation),
+                                      _ptr(joint_rotations), _ptr(trans), _ptr(global_mask), _ptr(rotation_mask),
+                                      _ptr(losses), _ptr(gg), _ptr(gj), _ptr(gt)), "smalfit_temporal")
+    return losses, gg, gj, gt
+
+
 def rodrigues(theta):
     lib = _lib.load()
     count = int(theta.shape[0])

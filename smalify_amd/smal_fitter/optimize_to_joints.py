@@ -1,0 +1,87 @@
+"""Counterpart of reference smal_fitter/optimize_to_joints.py: the stage / epoch driver.
+
+`main()` runs the fused on-device loop (smalify_amd.fitter.FusedFitter) with the reference's schedule and
+writes the same per-frame checkpoint files (st{stage}_ep{epoch}.pkl / .ply, final st10_ep0).  Dataset
+loading (BADJA / StanfordExtra json + images) is outside the accelerated path: pass the reference loader's
+output tuple `(rgb, sil, joints, visibility), filenames` to `fit_sequence`."""
+from __future__ import annotations
+
+import os
+import pickle as pkl
+
+import numpy as np
+import torch
+
+from .. import config, engine as eng, fitter as fit, model_io
+
+
+def write_ply(path, vertices, faces):
+    """binary little-endian PLY (replaces trimesh.Trimesh(...).export, optimize_to_joints.py:51-53)"""
+    v = np.ascontiguousarray(vertices, dtype="<f4")
+    f = np.asarray(faces).astype("<i4")
+    with open(path, "wb") as fh:
+        fh.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\n"
+                  "property float z\nelement face %d\nproperty list uchar int vertex_indices\nend_header\n"
+                  % (len(v), len(f))).encode())
+        fh.write(v.tobytes())
+        rec = np.empty(len(f), dtype=[("n", "u1"), ("i", "<i4", (3,))])
+        rec["n"] = 3
+        rec["i"] = f
+        fh.write(rec.tobytes())
+
+
+class ImageExporter:
+    """same directory layout and file names as the reference's exporter (optimize_to_joints.py:25-53)"""
+
+    def __init__(self, output_dir, filenames):
+        os.makedirs(output_dir, exist_ok=True)
+        self.output_dirs = []
+        for filename in filenames:
+            d = os.path.join(output_dir, os.path.splitext(filename)[0])
+            os.makedirs(d, exist_ok=True)
+            self.output_dirs.append(d)
+        self.stage_id = 0
+        self.epoch_name = 0
+
+    def export(self, collage_np, batch_id, global_id, img_parameters, vertices, faces):
+        stem = os.path.join(self.output_dirs[global_id], "st{0}_ep{1}".format(self.stage_id, self.epoch_name))
+        with open(stem + ".pkl", "wb") as f:
+            pkl.dump(img_parameters, f)
+        v = vertices[batch_id]
+        write_ply(stem + ".ply", v.cpu().numpy() if isinstance(v, torch.Tensor) else v, faces)
+
+
+def fit_sequence(data, filenames, model_data, pose_prior, shape_prior, use_unity_prior=True, output_dir=None,
+                 window_size=None, opt_weights=None, iters_scale=1.0):
+    """Runs the complete schedule on one sequence; returns the FusedFitter (parameters stay on the GPU)."""
+    rgb, sil, joints, vis = data
+    S = int(sil.shape[-1])
+    dm = eng.DeviceModel(model_data)
+    engine = eng.Engine(dm, int(joints.shape[0]), S)
+    engine.set_pose_prior(*pose_prior)
+    engine.set_shape_prior(*shape_prior)
+    f = fit.FusedFitter(engine, joints, vis, sil, window_size or config.WINDOW_SIZE, use_unity_prior,
+                        mean_betas=shape_prior[1][:20], mean_log_scales=shape_prior[1][20:26] if use_unity_prior else None)
+    exporter = ImageExporter(output_dir, filenames) if output_dir else None
+
+    def export(fitter, stage_id, epoch_id):
+        if exporter is None:
+            return
+        verts = torch.empty(fitter.N, dm.num_verts, 3, device=engine.device)
+        W = np.array(config.OPT_WEIGHTS if opt_weights is None else opt_weights).T
+        fitter.evaluate(W[min(stage_id, 3)][:6], 0.0, min(stage_id, 3), want=(), verts_out=verts)
+        for d, params, v in zip(exporter.output_dirs, fitter.frame_parameters(), verts.cpu().numpy()):
+            stem = os.path.join(d, "st{0}_ep{1}".format(stage_id, epoch_id))
+            with open(stem + ".pkl", "wb") as fh:
+                pkl.dump(params, fh)
+            write_ply(stem + ".ply", v, model_data.faces)
+
+    f.run_schedule(opt_weights, iters_scale, on_visualize=export)
+    export(f, 10, 0)                                   # final stage (optimize_to_joints.py:142-144)
+    return f
+
+
+def main():
+    raise SystemExit("smalify_amd.smal_fitter.optimize_to_joints.main: load a sequence with the reference's "
+                     "data_loader and call fit_sequence(data, filenames, model_io.load_smal_model(...), "
+                     "model_io.load_pose_prior(...), model_io.unity_shape_prior(...)).")

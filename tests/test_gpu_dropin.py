@@ -1,0 +1,215 @@
+"""GPU tests of the drop-in layer: the reference's class / function surface backed by HIP.
+
+The strongest check: the reference's own stage loop semantics (new torch.optim.Adam per stage, stage-0
+freezing, torso-only visibility, window accumulation, get_temporal) driven over *our* SMALFitter reproduces
+the parameter trajectory recorded from the *reference's* SMALFitter (tests/golden, G8)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import smal_oracle as so  # noqa: E402
+from smalify_amd import config as cfg  # noqa: E402
+from smalify_amd import synthetic  # noqa: E402
+from tests.parity_cases import rel  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def md():
+    return synthetic.synthetic_model(seed=0, shape_family_id=1)
+
+
+def _data(golden):
+    N, S = golden["g6_target_joints"].shape[0], int(golden["g6_image_size"])
+    return (torch.zeros(N, 3, S, S), torch.zeros(N, 1, S, S), torch.from_numpy(golden["g6_target_joints"]),
+            torch.from_numpy(golden["g6_visibility"])), N, S
+
+
+def _make_fitter(golden, md, window):
+    from smalify_amd.smal_fitter.smal_fitter import SMALFitter
+    data, N, S = _data(golden)
+    return SMALFitter("cuda", data, window, 1, True, model_data=md,
+                      pose_prior_data=(golden["pose_prec"], golden["pose_mean"], golden["pose_mask"]),
+                      shape_prior_data=(golden["unity_prec"], golden["unity_mean"]))
+
+
+def test_smal_module_matches_reference_golden(golden, md):
+    from smalify_amd.smal_model.smal_torch import SMAL
+    smal = SMAL("cuda", shape_family_id=1, model_data=md)
+    beta = torch.tensor(golden["g3_beta"], device="cuda", requires_grad=True)
+    theta = torch.tensor(golden["g3_theta"], device="cuda", requires_grad=True)
+    ls = torch.tensor(golden["g3_ls"], device="cuda", requires_grad=True)
+    verts, joints, Rs, v_shaped = smal(beta, theta, betas_logscale=ls)
+    vsel = torch.from_numpy(golden["g3_vsel"]).cuda()
+    assert rel(verts[:, vsel].detach().cpu(), golden["g3_verts"]) < 1e-5
+    assert rel(joints.detach().cpu(), golden["g3_joints"]) < 1e-5
+    assert rel(Rs.cpu(), golden["g3_Rs"]) < 1e-5
+    assert rel(v_shaped[:, vsel].cpu(), golden["g3_vshaped"]) < 1e-5
+    func = (verts[:, vsel] * torch.from_numpy(golden["g3_wv"]).cuda()).sum() + \
+           (joints * torch.from_numpy(golden["g3_wj"]).cuda()).sum()
+    func.backward()
+    assert rel(beta.grad.cpu(), golden["g3_dbeta"]) < 2e-4
+    assert rel(theta.grad.cpu(), golden["g3_dtheta"]) < 2e-4
+    assert rel(ls.grad.cpu(), golden["g3_dls"]) < 2e-4
+    assert smal.faces.shape == (7774, 3) and smal.faces.dtype == torch.int64
+
+
+def test_batch_rodrigues_matches_reference_golden(golden):
+    from smalify_amd.smal_model.batch_lbs import batch_rodrigues
+    R = batch_rodrigues(torch.from_numpy(golden["g1_theta"]).cuda())
+    assert np.abs(R.cpu().numpy() - golden["g1_R"]).max() < 5e-6
+
+
+def test_prior_matches_reference_golden(golden, md):
+    from smalify_amd.smal_model.smal_torch import SMAL
+    from smalify_amd.smal_fitter.priors.pose_prior_35 import Prior
+    SMAL("cuda", shape_family_id=1, model_data=md)
+    prior = Prior(None, "cuda", prior_data=(golden["pose_prec"], golden["pose_mean"], golden["pose_mask"]))
+    x = torch.tensor(golden["g4_x"], device="cuda", requires_grad=True)
+    val = prior(x)
+    val.mean().backward()
+    assert rel(val.detach().cpu(), golden["g4_val"]) < 1e-5
+    assert rel(x.grad.cpu(), golden["g4_dx"]) < 1e-5
+    assert abs(prior(torch.zeros(1, 35, 3, device="cuda")).mean().item() - 0.80639112) < 1e-5   # SURVEY §8c known answer
+
+
+def test_renderer_module(md):
+    """Renderer.forward: shapes, (row, col) keypoints and gradients vs the oracle."""
+    from smalify_amd.smal_model.smal_torch import SMAL
+    from smalify_amd.smal_fitter.p3d_renderer import Renderer
+    from tests import parity_cases as pc
+    smal = SMAL("cuda", shape_family_id=1, model_data=md)
+    S, M = 64, 2
+    p = pc.random_pose(M, 31)
+    theta = torch.tensor(np.concatenate([p["global_rotation"][:, None], p["joint_rotations"]], 1), device="cuda")
+    with torch.no_grad():
+        verts, joints, _, _ = smal(torch.tensor(np.tile(p["betas"], (M, 1)), device="cuda"), theta,
+                                   betas_logscale=torch.tensor(np.tile(p["log_beta_scales"], (M, 1)), device="cuda"))
+        verts = verts + torch.tensor(p["trans"], device="cuda")[:, None]
+        pts = (joints + torch.tensor(p["trans"], device="cuda")[:, None])[:, cfg.CANONICAL_MODEL_JOINTS]
+    verts = verts.clone().requires_grad_(True)
+    pts = pts.clone().requires_grad_(True)
+    renderer = Renderer(S, "cuda", model=smal.device_model)
+    sil, proj = renderer(verts, pts, smal.faces.unsqueeze(0).expand(M, -1, -1))
+    assert sil.shape == (M, 1, S, S) and proj.shape == (M, 25, 2)
+    w = torch.randn(M, 1, S, S, device="cuda")
+    wp = torch.randn(M, 25, 2, device="cuda")
+    ((sil * w).sum() + (proj * wp).sum()).backward()
+    v64 = verts.detach().cpu().double().requires_grad_(True)
+    p64 = pts.detach().cpu().double().requires_grad_(True)
+    om = so.OracleModel(md)
+    sil_o = so.soft_silhouette(v64, om.faces, S)
+    proj_o = so.project_points(p64, S)
+    ((sil_o * w[:, 0].cpu().double()).sum() + (proj_o * wp.cpu().double()).sum()).backward()
+    assert np.abs(sil[:, 0].detach().cpu().numpy() - sil_o.detach().numpy()).max() < 2e-3
+    assert np.abs(proj.detach().cpu().numpy() - proj_o.detach().numpy()).max() < 1e-3
+    assert rel(verts.grad.cpu(), v64.grad) < 1e-2
+    assert rel(pts.grad.cpu(), p64.grad) < 1e-5
+    with pytest.raises(NotImplementedError):
+        renderer(verts, pts, None, render_texture=True)
+
+
+def _reference_style_loop(f, golden, vis_full):
+    """the reference's driver semantics (optimize_to_joints.py:90-137) over a SMALFitter-like module"""
+    W = np.array(cfg.OPT_WEIGHTS).T
+    hist = []
+    N = f.num_images
+    snaps = {}
+    for stage_id, its in golden["g8_schedule"]:
+        weights = (golden["g6_w0"] if stage_id == 0 else golden["g6_w1"])
+        w_temp, lr = W[stage_id][6], W[stage_id][8]
+        opt = torch.optim.Adam(f.parameters(), lr=lr, betas=(0.5, 0.999))
+        if stage_id == 0:
+            f.joint_rotations.requires_grad = False
+            f.betas.requires_grad = False
+            f.log_beta_scales.requires_grad = False
+            tv = f.target_visibility.clone()
+            f.target_visibility *= 0
+            f.target_visibility[:, cfg.TORSO_JOINTS] = tv[:, cfg.TORSO_JOINTS]
+        else:
+            f.joint_rotations.requires_grad = True
+            f.betas.requires_grad = True
+            f.log_beta_scales.requires_grad = True
+            f.target_visibility = vis_full.clone()          # CPU float tensor, like data[-1].clone()
+        for _ in range(int(its)):
+            acc = 0
+            opt.zero_grad()
+            for j in range(0, N, 2):
+                loss, _ = f(list(range(j, min(N, j + 2))), weights, stage_id)
+                acc = acc + loss.mean()
+            jl, gl, tl = f.get_temporal(w_temp)
+            acc = acc + jl + gl + tl
+            acc.backward()
+            opt.step()
+            hist.append(acc.item())
+        snaps[int(stage_id)] = {k: getattr(f, k).detach().cpu().numpy().copy()
+                                for k in ("global_rotation", "joint_rotations", "trans", "betas", "log_beta_scales")}
+    return hist, snaps
+
+
+def test_reference_driver_loop_over_dropin_fitter_reproduces_reference_trajectory(golden, md):
+    f = _make_fitter(golden, md, 2)
+    hist, snaps = _reference_style_loop(f, golden, torch.from_numpy(golden["g6_visibility"]))
+    assert np.allclose(hist, golden["g8_loss_history"], rtol=5e-4), (hist, golden["g8_loss_history"])
+    for stage in (0, 1):
+        for k, v in snaps[stage].items():
+            r = rel(v, golden["g8_after_stage%d_%s" % (stage, k)])
+            assert r < 5e-4, (stage, k, r)
+
+
+def test_fused_fitter_reproduces_reference_trajectory(golden, md):
+    """same 20 iterations through the fused on-device loop (FusedFitter + HIP Adam)"""
+    from smalify_amd import engine as eng, fitter as fit
+    data, N, S = _data(golden)
+    e = eng.Engine(eng.DeviceModel(md), N, S)
+    e.set_pose_prior(golden["pose_prec"], golden["pose_mean"], golden["pose_mask"])
+    e.set_shape_prior(golden["unity_prec"], golden["unity_mean"])
+    f = fit.FusedFitter(e, golden["g6_target_joints"], golden["g6_visibility"], np.zeros((N, S, S), np.float32), 2,
+                        True, golden["unity_mean"][:20], golden["unity_mean"][20:26])
+    W = np.array(cfg.OPT_WEIGHTS).T
+    hist = []
+    for stage_id, its in golden["g8_schedule"]:
+        weights = golden["g6_w0"] if stage_id == 0 else golden["g6_w1"]
+        f.begin_stage(int(stage_id))
+        for _ in range(int(its)):
+            f.step(weights, float(W[stage_id][6]), float(W[stage_id][8]), int(stage_id))
+            hist.append(float(f.losses.sum().item()))
+        for k in ("global_rotation", "joint_rotations", "trans", "betas", "log_beta_scales"):
+            r = rel(f.p[k].cpu().numpy(), golden["g8_after_stage%d_%s" % (stage_id, k)])
+            assert r < 5e-4, (stage_id, k, r)
+    assert np.allclose(hist, golden["g8_loss_history"], rtol=5e-4)
+
+
+def test_checkpoint_layout_roundtrip(golden, md, tmp_path):
+    """FusedFitter writes the reference's per-frame dict layout; SMALFitter.load_checkpoint reads it with the
+    reference's semantics (betas / scales averaged over frames) — compared with the reference's own result (G9)."""
+    from smalify_amd import engine as eng, fitter as fit
+    data, N, S = _data(golden)
+    e = eng.Engine(eng.DeviceModel(md), N, S)
+    f = fit.FusedFitter(e, golden["g6_target_joints"], golden["g6_visibility"], np.zeros((N, S, S), np.float32), N,
+                        True, golden["unity_mean"][:20], golden["unity_mean"][20:26])
+    dirs = [str(tmp_path / ("%04d" % i)) for i in range(N)]
+    f.export_checkpoints(dirs, 10, 0)
+    with open(os.path.join(dirs[1], "st10_ep0.pkl"), "rb") as fh:
+        d = pickle.load(fh)
+    assert sorted(d) == ["betas", "global_rotation", "joint_rotations", "log_betascale", "trans"]
+    assert d["global_rotation"].shape == (3,) and d["joint_rotations"].shape == (34, 3) and d["betas"].shape == (20,)
+    assert d["log_betascale"].shape == (6,) and d["trans"].shape == (3,)
+    assert all(v.dtype == np.float32 for v in d.values())
+    # reference-written frames (G9) -> our load_checkpoint == reference's load_checkpoint
+    ck = tmp_path / "ref"
+    for i in range(N):
+        os.makedirs(ck / ("%04d" % i))
+        with open(ck / ("%04d" % i) / "st10_ep0.pkl", "wb") as fh:
+            pickle.dump({k: golden["g9_frames_" + k][i] for k in d}, fh)
+    g = _make_fitter(golden, md, N)
+    g.load_checkpoint(str(ck), "st10_ep0")
+    f.load_checkpoint(str(ck), "st10_ep0")
+    for k in ("global_rotation", "joint_rotations", "trans", "betas", "log_beta_scales"):
+        ref = golden["g9_loaded_" + k]
+        assert np.allclose(getattr(g, k).detach().cpu().numpy(), ref, atol=1e-6), k
+        assert np.allclose(f.p[k].cpu().numpy(), ref, atol=1e-6), k
