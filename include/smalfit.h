@@ -62,12 +62,13 @@ int smalfit_engine_status(smalfit_engine* engine, void* stream, int* status_bits
 /* optional: time sections of smalfit_fit_eval with HIP events recorded on the caller's stream.
  * profile_begin arms up to max_evals evaluations; profile_end synchronises `stream`, and returns the summed
  * milliseconds and the number of timed evaluations per section. */
-#define SMALFIT_NUM_SECTIONS 5
-#define SMALFIT_SEC_LBS_FWD 0    /* shape + pose + skin + joints kernels          */
-#define SMALFIT_SEC_RASTER_BIN 1 /* face records + raster_sweep_kernel (count, log-alpha) */
-#define SMALFIT_SEC_RASTER_FWD 2 /* raster_resolve_kernel (K-nearest product)     */
-#define SMALFIT_SEC_RASTER_BWD 3 /* raster_bwd_kernel alone                       */
-#define SMALFIT_SEC_LBS_BWD 4    /* vertex / dA / pose-blend / chain adjoints     */
+#define SMALFIT_NUM_SECTIONS 6
+#define SMALFIT_SEC_LBS_FWD 0        /* shape + pose + skin + joints kernels                     */
+#define SMALFIT_SEC_RASTER_SWEEP 1   /* accumulator memset + face_bbox_kernel + raster_sweep_kernel */
+#define SMALFIT_SEC_RASTER_SELECT 2  /* raster_select_kernel alone (K-nearest selection)          */
+#define SMALFIT_SEC_RASTER_BWD 3     /* raster_bwd_kernel alone                                   */
+#define SMALFIT_SEC_LBS_BWD 4        /* vertex / dA / pose-blend / chain adjoints                 */
+#define SMALFIT_SEC_RASTER_RESOLVE 5 /* raster_resolve_kernel alone                               */
 int smalfit_engine_profile_begin(smalfit_engine* engine, int max_evals);
 int smalfit_engine_profile_end(smalfit_engine* engine, void* stream, float* ms_total, int* counts);
 

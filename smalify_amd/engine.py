@@ -104,15 +104,15 @@ class Engine:
               "smalfit_engine_set_shape_prior")
         self.shape_prior_dim = int(m.shape[0])
 
-    SECTIONS = ("lbs_fwd", "raster_bin", "raster_fwd", "raster_bwd", "lbs_bwd")
+    SECTIONS = ("lbs_fwd", "raster_sweep", "raster_select", "raster_bwd", "lbs_bwd", "raster_resolve")
 
     def profile_begin(self, max_evals):
         check(self.lib.smalfit_engine_profile_begin(self.handle, int(max_evals)), "smalfit_engine_profile_begin")
 
     def profile_end(self):
         """-> {section: (total_ms, count)} measured with HIP events on the current stream."""
-        ms = (C.c_float * 5)()
-        cnt = (C.c_int * 5)()
+        ms = (C.c_float * 6)()
+        cnt = (C.c_int * 6)()
         check(self.lib.smalfit_engine_profile_end(self.handle, _stream(), ms, cnt), "smalfit_engine_profile_end")
         return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(self.SECTIONS)}
 
