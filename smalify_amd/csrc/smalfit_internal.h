@@ -75,8 +75,8 @@ struct AssembleArgs {
   const float* loss_part;
   const float* loss_betas;
   const float* tile_loss;
-  const float* qloss;      // weighted silhouette loss of the queued (K-truncated) pixels
-  const int* qcount;
+  const float* qloss;      // weighted silhouette loss of the queued (K-truncated) pixels, one partial per select block
+  int nqblk;
   float* g_betas;
   float* g_ls;
   float* g_grot;

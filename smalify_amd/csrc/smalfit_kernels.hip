@@ -474,7 +474,7 @@ shape_prior_kernel(const float* __restrict__ betas, const float* __restrict__ lo
 // ------------------------------------------------------------------------------------------------
 constexpr int kRectFaces = 8;             // faces per entry of the union-box index
 constexpr int kSweepFaces = 128;          // faces per sweep block
-constexpr int kAccWin = 64;               // LDS accumulator window edge (pixels)
+constexpr int kAccWin = 48;               // LDS accumulator window edge (pixels)
 constexpr int kCountShift = 50;
 constexpr float kLogFix = 268435456.0f;   // 2^28
 
@@ -494,7 +494,11 @@ __device__ __forceinline__ bool box_contains(int2 b, int x, int y) {
   return (b.x & 0xffff) <= x && x <= (b.x >> 16) && (b.y & 0xffff) <= y && y <= (b.y >> 16);
 }
 __device__ __forceinline__ unsigned long long pack_candidate(float d) {
-  return (1ull << kCountShift) | (unsigned long long)(-log2_one_minus_prob(d) * kLogFix);
+  // count in the top bits, -log2(1 - p) in [0, 256] as 2^-28 fixed point (integer and fractional part separately:
+  // there is no native float -> u64 conversion)
+  const float f = -log2_one_minus_prob(d);
+  const float ip = floorf(f);
+  return (1ull << kCountShift) | ((unsigned long long)(unsigned)ip << 28) | (unsigned long long)(unsigned)((f - ip) * kLogFix);
 }
 
 // 5a: per-face validity, conservative pixel box, packed record; union box per 32 faces
@@ -666,20 +670,27 @@ raster_resolve_kernel(int S, int M, int window, float w_sil, const unsigned long
 }
 
 // 5d: select.  Persistent grid; one wave per queued pixel: it walks the union boxes (8 faces each)
-// containing the pixel, evaluates those faces (lane per face), compacts the candidates into LDS in face
-// order, finds the K-th smallest depth exactly (4 x 8-bit radix select on an order-preserving key) and
-// multiplies the K nearest (1 - p) in a fixed order.
+// containing the pixel, evaluates those faces (lane per face, record loads software-prefetched), compacts
+// the candidates into LDS in face order, finds the K-th smallest depth exactly (4 x 8-bit radix select on an
+// order-preserving key) and multiplies the K nearest (1 - p) in a fixed order.
 constexpr int kCandCap = 1024;            // candidates per pixel kept in LDS; beyond: multi-pass re-evaluation
-constexpr int kHitCap = 1024;             // union boxes containing a pixel kept in LDS
+constexpr int kHitCap = 1024;             // union boxes containing a pixel kept in LDS (aliases the candidate buffer)
+constexpr int kCoverCap = 2048;           // faces whose box covers the pixel, kept in LDS (u16 ids)
 
 __global__ void __launch_bounds__(256)
 raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4* __restrict__ frec,
-                     const int4* __restrict__ brect, const int* __restrict__ qcount, const int* __restrict__ queue,
-                     const float* __restrict__ tsil, float* __restrict__ sil_out, float2* __restrict__ gz,
-                     float* __restrict__ qloss /*[queue length]: weighted |sil - target| or null*/) {
+                     const int4* __restrict__ brect, const int2* __restrict__ fbox, const int* __restrict__ qcount,
+                     const int* __restrict__ queue, const float* __restrict__ tsil, float* __restrict__ sil_out,
+                     float2* __restrict__ gz,
+                     float* __restrict__ qloss /*[gridDim.x]: weighted |sil - target| summed per block, or null*/, int dbg) {
   __shared__ unsigned hist[4][256];
   __shared__ float2 cand[4][kCandCap];
-  __shared__ int hits[4][kHitCap];
+  __shared__ unsigned short fids[4][kCoverCap];
+  // the union-box hit list is consumed (stage A) before the first candidate is written (stage B): share storage
+  int (*hits)[2 * kCandCap] = reinterpret_cast<int (*)[2 * kCandCap]>(&cand[0][0]);
+  static_assert(kHitCap <= 2 * kCandCap, "hit list must fit in the candidate buffer");
+  __shared__ float wloss[4];
+  float lacc = 0.f;
   constexpr int K = kFacesPerPixel;
   constexpr int RC = kCandCap / 64;
   constexpr int RPI = 64 / kRectFaces;      // union boxes handled per wave iteration
@@ -695,32 +706,79 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
     const float ppx = pix_to_ndc(pcol, inv_s), ppy = pix_to_ndc(prow, inv_s);
     const int4* br = brect + (size_t)n * nrect;
     const float4* fr = frec + (size_t)n * F * 3;
-    // union boxes containing the pixel (ascending)
+    // union boxes containing the pixel (ascending); 4 independent loads in flight per round
     int nh = 0;
-    for (int r0 = 0; r0 < nrect; r0 += 64) {
-      const int ri = r0 + lane;
-      bool hit = false;
-      if (ri < nrect) { const int4 b = br[ri]; hit = b.x <= pcol && pcol <= b.y && b.z <= prow && prow <= b.w; }
-      const unsigned long long bal = __ballot(hit);
-      if (hit) { const int pos = nh + __popcll(bal & ((1ull << lane) - 1ull)); if (pos < kHitCap) hits[w][pos] = ri; }
-      nh += __popcll(bal);
+    for (int r0 = 0; r0 < nrect; r0 += 256) {
+      int4 b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ri = r0 + u * 64 + lane;
+        b[u] = (ri < nrect) ? br[ri] : make_int4(1, 0, 1, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool hit = b[u].x <= pcol && pcol <= b[u].y && b[u].z <= prow && prow <= b[u].w;
+        const unsigned long long bal = __ballot(hit);
+        if (hit) { const int pos = nh + __popcll(bal & ((1ull << lane) - 1ull)); if (pos < kHitCap) hits[w][pos] = r0 + u * 64 + lane; }
+        nh += __popcll(bal);
+      }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (dbg & 1) continue;
+    // faces whose pixel box covers the pixel (ascending ids): 8-byte box test only, nothing evaluated yet
+    const int2* fb = fbox + (size_t)n * F;
+    int ncov = 0;
+    if (nh <= kHitCap) {
+      for (int j = 0; j < nh; j += 4 * RPI) {
+        int ff[4];
+        int2 bx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int hj = j + u * RPI + lane / kRectFaces;
+          ff[u] = -1;
+          bx[u] = make_int2(1, 1);
+          if (hj < nh) {
+            const int f = hits[w][hj] * kRectFaces + (lane & (kRectFaces - 1));
+            if (f < F) { ff[u] = f; bx[u] = fb[f]; }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool cov = ff[u] >= 0 && box_contains(bx[u], pcol, prow);
+          const unsigned long long bal = __ballot(cov);
+          if (cov) { const int pos = ncov + __popcll(bal & ((1ull << lane) - 1ull)); if (pos < kCoverCap) fids[w][pos] = (unsigned short)ff[u]; }
+          ncov += __popcll(bal);
+        }
+      }
+    }
+    if (dbg & 2) continue;
+    const bool compact = (nh <= kHitCap) && (ncov <= kCoverCap) && (F <= 65536);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // visit every candidate of the pixel in face order: fn(valid, pz, d) is called wave-wide
     auto scan_candidates = [&](auto&& fn) {
-      if (nh <= kHitCap) {
-        for (int j = 0; j < nh; j += RPI) {
-          const int hj = j + lane / kRectFaces;
+      if (compact) {
+        float4 pa, pb, pc;
+        bool plive;
+        auto prefetch = [&](int j) {
+          plive = (j + lane) < ncov;
+          if (plive) {
+            const int ff = fids[w][j + lane];
+            pa = fr[(size_t)ff * 3]; pb = fr[(size_t)ff * 3 + 1]; pc = fr[(size_t)ff * 3 + 2];
+          }
+        };
+        prefetch(0);
+        for (int j = 0; j < ncov; j += 64) {
+          const float4 a = pa, b = pb, c = pc;
+          const bool live = plive;
+          if (j + 64 < ncov) prefetch(j + 64);
           bool ok = false;
           PixEval e; e.pz = 0.f; e.d = 0.f;
-          if (hj < nh) {
-            const int ff = hits[w][hj] * kRectFaces + (lane & (kRectFaces - 1));
-            if (ff < F) {
-              FaceRec r; int2 box;
-              load_face_rec(fr + (size_t)ff * 3, r, box);
-              if (box_contains(box, pcol, prow)) ok = face_pixel_eval(r, ppx, ppy, e);
-            }
+          if (live) {
+            FaceRec r;
+            make_face_rec(a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, r);
+            ok = face_pixel_eval(r, ppx, ppy, e);
           }
           fn(ok, e.pz, e.d);
         }
@@ -749,18 +807,8 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
     });
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (dbg & 4) continue;
     const bool cached = nc <= kCandCap;
-    unsigned key[RC];
-    float val[RC];
-    if (cached) {
-#pragma unroll
-      for (int i = 0; i < RC; ++i) {
-        const int j = lane + 64 * i;
-        key[i] = 0xffffffffu;
-        val[i] = 1.0f;
-        if (j < nc) { const float2 ev = cand[w][j]; key[i] = orderable(ev.x); val[i] = ev.y; }
-      }
-    }
     unsigned prefix = 0u;
     int need = K;
     for (int pass = 0; pass < 4; ++pass) {
@@ -770,11 +818,13 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       if (cached) {
-#pragma unroll
+#pragma unroll 4
         for (int i = 0; i < RC; ++i) {
-          const bool live = (lane + 64 * i) < nc;
-          const bool in = live && ((pass == 0) || ((key[i] >> (shift + 8)) == (prefix >> (shift + 8))));
-          if (in) atomicAdd(&hist[w][(key[i] >> shift) & 255u], 1u);
+          const int j = lane + 64 * i;
+          if (j < nc) {
+            const unsigned kk = orderable(cand[w][j].x);
+            if ((pass == 0) || ((kk >> (shift + 8)) == (prefix >> (shift + 8)))) atomicAdd(&hist[w][(kk >> shift) & 255u], 1u);
+          }
         }
       } else {
         scan_candidates([&](bool ok, float pz, float d) {
@@ -816,8 +866,11 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
     }
     float a = 1.0f;
     if (cached) {
-#pragma unroll
-      for (int i = 0; i < RC; ++i) if (key[i] <= prefix && (lane + 64 * i) < nc) a *= val[i];
+#pragma unroll 4
+      for (int i = 0; i < RC; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nc) { const float2 ev = cand[w][j]; if (orderable(ev.x) <= prefix) a *= ev.y; }
+      }
     } else {
       scan_candidates([&](bool ok, float pz, float d) { if (ok && orderable(pz) <= prefix) a *= one_minus_prob(d); });
     }
@@ -836,9 +889,14 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
         gx = -wn * sgn * a * (1.0f / kSigma);
       }
       if (gz) gz[pi] = make_float2(gx, from_orderable(prefix));
-      if (qloss) qloss[qi] = l;
+      lacc += l;
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  if (qloss) {
+    if (lane == 0) wloss[w] = lacc;
+    __syncthreads();
+    if (t == 0) qloss[blockIdx.x] = (wloss[0] + wloss[1]) + (wloss[2] + wloss[3]);
   }
 }
 
@@ -1265,10 +1323,7 @@ assemble_kernel(AssembleArgs a) {
         lsil += a.tile_loss[k] * (a.w_sil / ((float)Bn * (float)a.S * (float)a.S));
       }
     }
-    if (a.qloss && a.qcount) {
-      const int nq = *a.qcount;
-      for (int k = t; k < nq; k += 256) lsil += a.qloss[k];
-    }
+    if (a.qloss) for (int k = t; k < a.nqblk; k += 256) lsil += a.qloss[k];
     lsil = block_sum(lsil, red);
     if (t < 8) {
       float acc = 0.f;

@@ -20,6 +20,15 @@
 
 namespace smalfit {
 
+// 1/x: v_rcp_f32 (1 ulp) in device code, IEEE division on the host (test shim)
+SMALFIT_HD float recip(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.0f / x;
+#endif
+}
+
 constexpr int kJoints = 35;
 constexpr int kPoseFeat = 306;
 constexpr int kModelJoints = 41;
@@ -132,11 +141,11 @@ SMALFIT_HD bool make_face_rec(float ax, float ay, float az, float bx, float by, 
   const float l1 = r.e1x * r.e1x + r.e1y * r.e1y;
   const float l2 = r.e2x * r.e2x + r.e2y * r.e2y;
   const float l3 = r.e3x * r.e3x + r.e3y * r.e3y;
-  r.il1 = l1 > kEps ? 1.0f / l1 : 0.0f;  r.t01 = l1 > kEps ? 0.0f : 1.0f;
-  r.il2 = l2 > kEps ? 1.0f / l2 : 0.0f;  r.t02 = l2 > kEps ? 0.0f : 1.0f;
-  r.il3 = l3 > kEps ? 1.0f / l3 : 0.0f;  r.t03 = l3 > kEps ? 0.0f : 1.0f;
+  r.il1 = l1 > kEps ? recip(l1) : 0.0f;  r.t01 = l1 > kEps ? 0.0f : 1.0f;
+  r.il2 = l2 > kEps ? recip(l2) : 0.0f;  r.t02 = l2 > kEps ? 0.0f : 1.0f;
+  r.il3 = l3 > kEps ? recip(l3) : 0.0f;  r.t03 = l3 > kEps ? 0.0f : 1.0f;
   r.area = r.e2x * r.e1y - r.e2y * r.e1x;            // E(c; a, b) = (c-a) x (b-a)
-  r.inv_den = 1.0f / (r.area + kEps);
+  r.inv_den = recip(r.area + kEps);
   // pz = w0 az + w1 bz + w2 cz with barycentrics over (area + eps) is affine in the pixel
   const float da = cz - az, db = az - bz;
   r.gzx = r.inv_den * (da * r.e1y + db * r.e2y);
@@ -188,16 +197,17 @@ SMALFIT_HD bool face_pixel_eval(const FaceRec& r, float px, float py, PixEval& o
 }
 
 // 1 - p = sigmoid(d / sigma)
-SMALFIT_HD float one_minus_prob(float d) { return 1.0f / (1.0f + expf(-d * (1.0f / kSigma))); }
+SMALFIT_HD float one_minus_prob(float d) { return recip(1.0f + expf(-d * (1.0f / kSigma))); }
 // p = sigmoid(-d / sigma)
-SMALFIT_HD float prob(float d) { return 1.0f / (1.0f + expf(d * (1.0f / kSigma))); }
+SMALFIT_HD float prob(float d) { return recip(1.0f + expf(d * (1.0f / kSigma))); }
 
-// log2(1 - p) = log2 sigmoid(x), x = d / sigma, accurate for |x| large or small:
-// logsigmoid(x) = min(x, 0) - log1p(exp(-|x|)).  Clamped at -256 (alpha underflows to 0 long before).
+// log2(1 - p) = log2 sigmoid(x), x = d / sigma = min(x,0) log2(e) - log2(1 + 2^(-|x| log2 e)).
+// Forming 1 + t in float costs at most 6e-8 absolute in the logarithm, i.e. <= 6e-8 relative in alpha per
+// candidate -- the same as one rounded multiplication.  Clamped at -256 (alpha underflows long before).
 SMALFIT_HD float log2_one_minus_prob(float d) {
-  const float x = d * (1.0f / kSigma);
-  const float ls = fminf(x, 0.0f) - log1pf(expf(-fabsf(x)));
-  return fmaxf(ls * 1.4426950408889634f, -256.0f);
+  const float x2 = d * (1.4426950408889634f / kSigma);
+  const float ls2 = fminf(x2, 0.0f) - log2f(1.0f + exp2f(-fabsf(x2)));
+  return fmaxf(ls2, -256.0f);
 }
 
 // pixel centre in NDC (both image axes flipped)

@@ -201,16 +201,23 @@ def case_fit(M=4, S=64, window=2, stage=2, seed=21, trainable=None):
     return out
 
 
-def case_fit_golden(golden, tag, window, stage):
-    """HIP fitter evaluation against the *reference's own* outputs (tests/golden, no silhouette)."""
-    md, _, dm = get_model()
+def case_fit_golden(golden, tag, window, stage, family1=True):
+    """HIP fitter evaluation against the *reference's own* outputs (tests/golden, no silhouette).
+    family1=False: SMAL cluster prior (20-dim) with per-frame limb scales (reference smal_fitter.py:62-72)."""
     S = int(golden["g6_image_size"])
     N = golden["g6_target_joints"].shape[0]
-    key = ("golden_engine", S)
+    key = ("golden_engine", S, family1)
     if key not in _CACHE:
+        if family1:
+            dm = get_model()[2]
+        else:
+            dm = eng.DeviceModel(synthetic.synthetic_model(seed=0, shape_family_id=0))
         e = eng.Engine(dm, 8, S)
         e.set_pose_prior(golden["pose_prec"], golden["pose_mean"], golden["pose_mask"])
-        e.set_shape_prior(golden["unity_prec"], golden["unity_mean"])
+        if family1:
+            e.set_shape_prior(golden["unity_prec"], golden["unity_mean"])
+        else:
+            e.set_shape_prior(golden["fam0_prec"], golden["fam0_mean"])
         _CACHE[key] = e
     e = _CACHE[key]
     weights = golden["g6_w0"] if stage == 0 else golden["g6_w1"]

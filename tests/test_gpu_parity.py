@@ -55,6 +55,15 @@ def test_fitter_against_reference_golden(golden, tag, window, stage):
             assert v < 5e-4, (k, v)
 
 
+def test_fitter_non_unity_family_against_reference_golden(golden):
+    """shape family 0: 20-dim SMAL cluster prior, per-frame (N,6) limb scales trained without a regulariser"""
+    m = pc.case_fit_golden(golden, "g6_family0_w4", 4, 1, family1=False)
+    assert m["golden_total_rel"] < 1e-4, m
+    for k, v in m.items():
+        if k.startswith("golden_grad_"):
+            assert v < 5e-4, (k, v)
+
+
 @pytest.mark.parametrize("M,S,z,seed", [(2, 64, 1.45, 11), (1, 64, 0.0, 13), (1, 128, 1.3, 17)])
 def test_renderer(M, S, z, seed):
     m = pc.case_render(M, S, z, seed)
