@@ -63,6 +63,8 @@ struct AssembleArgs {
   float w_sil;
   const float* dbeta_part;
   const float* dJrest;
+  const float* dbetaJ;     // [M][NBall] d beta through the rest joints (chain_bwd_kernel)
+  int ngrp_beta;           // frame groups of dbeta_kernel
   const float* JS;
   const float* gb_prior;
   const float* gls_prior;

@@ -910,22 +910,18 @@ __global__ void gpix_from_dsil_kernel(size_t total, const float* __restrict__ si
 // 5d: backward, face-parallel gather (deterministic, no atomics).  16 lanes per face sweep the face's
 // pixel box in 4x4 patches; d(signed dist^2)/d(vertex) flows through the nearest edge only.
 __global__ void __launch_bounds__(256)
-raster_bwd_kernel(ModelDev m, int S, const float* __restrict__ proj, const int2* __restrict__ fbox,
-                  const float2* __restrict__ gz, float* __restrict__ dface /*[M][F][6]*/) {
+raster_bwd_kernel(int F, int S, const float4* __restrict__ frec, const float2* __restrict__ gz,
+                  float* __restrict__ dface /*[M][F][6]*/) {
   const int n = blockIdx.y;
   const int f = blockIdx.x * 16 + (threadIdx.x >> 4);
   const int sub = threadIdx.x & 15, lx = sub & 3, ly = sub >> 2;
   float ga[2] = {0.f, 0.f}, gb[2] = {0.f, 0.f}, gc[2] = {0.f, 0.f};
-  if (f < m.F) {
-    const int2 box = fbox[(size_t)n * m.F + f];
+  if (f < F) {
+    FaceRec r;
+    int2 box;
+    load_face_rec(frec + ((size_t)n * F + f) * 3, r, box);
     const int c0 = box.x & 0xffff, c1 = box.x >> 16, r0 = box.y & 0xffff, r1 = box.y >> 16;
     if (c0 <= c1) {
-      const int Vp = m.Vp;
-      const float* pv = proj + (size_t)n * 3 * Vp;
-      const int i0 = m.faces[f * 3], i1 = m.faces[f * 3 + 1], i2 = m.faces[f * 3 + 2];
-      FaceRec r;
-      make_face_rec(pv[i0], pv[Vp + i0], pv[2 * Vp + i0], pv[i1], pv[Vp + i1], pv[2 * Vp + i1],
-                    pv[i2], pv[Vp + i2], pv[2 * Vp + i2], r);
       const float inv_s = 1.0f / (float)S;
       const float2* gp = gz + (size_t)n * S * S;
       for (int ry = r0; ry <= r1; ry += 4) {
@@ -958,8 +954,8 @@ raster_bwd_kernel(ModelDev m, int S, const float* __restrict__ proj, const int2*
     gb[0] += __shfl_xor(gb[0], o, 64); gb[1] += __shfl_xor(gb[1], o, 64);
     gc[0] += __shfl_xor(gc[0], o, 64); gc[1] += __shfl_xor(gc[1], o, 64);
   }
-  if (f < m.F && sub == 0) {
-    float* o = dface + ((size_t)n * m.F + f) * 6;
+  if (f < F && sub == 0) {
+    float* o = dface + ((size_t)n * F + f) * 6;
     o[0] = ga[0]; o[1] = ga[1]; o[2] = gb[0]; o[3] = gb[1]; o[4] = gc[0]; o[5] = gc[1];
   }
 }
@@ -1129,18 +1125,24 @@ poseblend_bwd_kernel(ModelDev m, int M, int CS, const float* __restrict__ dvp,
 //     per-frame betas (blockIdx.y = frame): no sum over frames.
 __global__ void __launch_bounds__(256)
 dbeta_kernel(ModelDev m, int M, int nb, int shared, const float* __restrict__ dvp,
-             float* __restrict__ dbeta_part /*[nbs][gridDim.x][nb]*/) {
+             float* __restrict__ dbeta_part /*[nbs][gridDim.z * gridDim.x][nb]*/) {
   __shared__ float red[16];
   const int ncol = 3 * m.Vp;
   const int c = blockIdx.x * 256 + threadIdx.x;
   float g = 0.f;
   if (c < ncol) {
-    if (shared) for (int n = 0; n < M; ++n) g += dvp[(size_t)n * ncol + c];
-    else g = dvp[(size_t)blockIdx.y * ncol + c];
+    if (shared) {       // frames are split over blockIdx.z
+      const int per = (M + gridDim.z - 1) / gridDim.z;
+      const int n0 = blockIdx.z * per, n1 = min(M, n0 + per);
+      for (int n = n0; n < n1; ++n) g += dvp[(size_t)n * ncol + c];
+    } else {
+      g = dvp[(size_t)blockIdx.y * ncol + c];
+    }
   }
+  const size_t part = (size_t)blockIdx.y * gridDim.z * gridDim.x + (size_t)blockIdx.z * gridDim.x + blockIdx.x;
   for (int b = 0; b < nb; ++b) {
     const float s = block_sum((c < ncol) ? g * m.sd[(size_t)b * ncol + c] : 0.f, red);
-    if (threadIdx.x == 0) dbeta_part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * nb + b] = s;
+    if (threadIdx.x == 0) dbeta_part[part * nb + b] = s;
   }
 }
 
@@ -1153,7 +1155,7 @@ chain_bwd_kernel(ModelDev m, int M, const float* __restrict__ theta, const float
                  const float* __restrict__ Jrest, int j_stride, const float* __restrict__ dA,
                  const float* __restrict__ dpf_part, int CS, const float* __restrict__ dth_direct,
                  float* __restrict__ dtheta /*[M][105]*/, float* __restrict__ dls /*[M][6]*/,
-                 float* __restrict__ dJrest /*[M][105]*/) {
+                 float* __restrict__ dJrest /*[M][105]*/, float* __restrict__ dbetaJ /*[M][NBall] or null*/) {
   __shared__ float R[35][9], G[35][12], sc[35][3], J[35][3];
   __shared__ float dG[35][12], dR[35][9], dsc[35][3], dJ[35][3];
   __shared__ float dRp[9], dj[3];
@@ -1249,6 +1251,12 @@ chain_bwd_kernel(ModelDev m, int M, const float* __restrict__ theta, const float
     dls[(size_t)n * 6 + l] = acc;
   }
   for (int i = l; i < 105; i += 64) dJrest[(size_t)n * 105 + i] = dJ[i / 3][i % 3];
+  // rest joints are affine in beta (J = Jt + JS beta): d beta through the joints
+  if (dbetaJ && l < m.NBall) {
+    float acc = 0.f;
+    for (int i = 0; i < 105; ++i) acc = fmaf(dJ[i / 3][i % 3], m.JS[i * m.NBall + l], acc);
+    dbetaJ[(size_t)n * m.NBall + l] = acc;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1269,12 +1277,9 @@ assemble_kernel(AssembleArgs a) {
       float acc = 0.f;
       if (slice < 12 && b < a.nb) {
         const int nlo = a.betas_shared ? 0 : s, nhi = a.betas_shared ? M : s + 1;
-        const int total = (nhi - nlo) * 105;
-        for (int k = slice; k < total; k += 12) {
-          const int n = nlo + k / 105, i = k % 105;
-          acc = fmaf(a.dJrest[(size_t)n * 105 + i], a.JS[i * a.NBall + b], acc);
-        }
-        for (int blk = slice; blk < a.nblk_beta; blk += 12) acc += a.dbeta_part[((size_t)s * a.nblk_beta + blk) * a.nb + b];
+        for (int n = nlo + slice; n < nhi; n += 12) acc += a.dbetaJ[(size_t)n * a.NBall + b];
+        const int nparts = a.nblk_beta * a.ngrp_beta;
+        for (int blk = slice; blk < nparts; blk += 12) acc += a.dbeta_part[((size_t)s * nparts + blk) * a.nb + b];
         bsum[slice][b] = acc;
       }
       __syncthreads();
