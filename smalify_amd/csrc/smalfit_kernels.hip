@@ -474,7 +474,7 @@ shape_prior_kernel(const float* __restrict__ betas, const float* __restrict__ lo
 // ------------------------------------------------------------------------------------------------
 constexpr int kRectFaces = 8;             // faces per entry of the union-box index
 constexpr int kSweepFaces = 128;          // faces per sweep block
-constexpr int kAccWin = 48;               // LDS accumulator window edge (pixels)
+constexpr int kAccWin = 48;               // LDS accumulator window edge (pixels); outside: global atomics
 constexpr int kCountShift = 50;
 constexpr float kLogFix = 268435456.0f;   // 2^28
 
@@ -557,17 +557,22 @@ __device__ __forceinline__ bool load_face_rec(const float4* __restrict__ fr, Fac
   return make_face_rec(a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, r);
 }
 
-// 5b: sweep
+// 5b: sweep.  Two accumulators per pixel: A = number of candidates, B = packed (count, log sum) over the
+// candidates not farther than the pixel's depth threshold of the previous evaluation (gz.y; +inf for pixels that had
+// at most K candidates).  If B counts all candidates (and there are at most K), or exactly K of more than K, B's
+// set IS the K nearest (everything else is farther than the threshold): no selection needed this time.
 __global__ void __launch_bounds__(256)
-raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, unsigned long long* __restrict__ gacc /*[M][S*S]*/) {
+raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, const float2* __restrict__ gz_prev,
+                    unsigned long long* __restrict__ gacc /*[M][S*S][2]*/) {
   __shared__ __attribute__((aligned(16))) FaceRec recs[kSweepFaces];
   __shared__ int2 boxes[kSweepFaces];
-  __shared__ unsigned long long acc[kAccWin * kAccWin];
+  __shared__ unsigned long long accB[kAccWin * kAccWin];   // near candidates: count << 50 | log sum
+  __shared__ unsigned accA[kAccWin * kAccWin];             // all candidates: count
   __shared__ int rect[4];
   const int n = blockIdx.y, t = threadIdx.x;
   const int f0 = blockIdx.x * kSweepFaces;
   if (t < 4) rect[t] = (t & 1) ? -1 : 0x7fff;          // x0, x1, y0, y1
-  for (int i = t; i < kAccWin * kAccWin; i += 256) acc[i] = 0ull;
+  for (int i = t; i < kAccWin * kAccWin; i += 256) { accA[i] = 0u; accB[i] = 0ull; }
   __syncthreads();
   if (t < kSweepFaces) {
     int2 box = make_int2(1, 1);
@@ -585,7 +590,8 @@ raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, unsigned long
   __syncthreads();
   if (rect[1] < rect[0]) return;                        // no face of this block is on screen
   const int wx0 = rect[0], wy0 = rect[2];
-  unsigned long long* ga = gacc + (size_t)n * S * S;
+  unsigned long long* ga = gacc + (size_t)n * S * S * 2;
+  const float2* gzp = gz_prev + (size_t)n * S * S;
   const int sub = t & 15, lx = sub & 3, ly = sub >> 2, grp = t >> 4;
   const float inv_s = 1.0f / (float)S;
   for (int step = 0; step < kSweepFaces / 16; ++step) {
@@ -598,12 +604,18 @@ raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, unsigned long
       for (int cx = c0; cx <= c1; cx += 4) {
         const int col = cx + lx;
         if (row > r1 || col > c1) continue;
+        const float bound = gzp[row * S + col].y;
         PixEval e;
         if (!face_pixel_eval(recs[k], pix_to_ndc(col, inv_s), pix_to_ndc(row, inv_s), e)) continue;
-        const unsigned long long v = pack_candidate(e.d);
+        const bool near = e.pz <= bound;
         const int lxw = col - wx0, lyw = row - wy0;
-        if (lxw < kAccWin && lyw < kAccWin) atomicAdd(&acc[lyw * kAccWin + lxw], v);
-        else atomicAdd(&ga[row * S + col], v);
+        if (lxw < kAccWin && lyw < kAccWin) {
+          atomicAdd(&accA[lyw * kAccWin + lxw], 1u);
+          if (near) atomicAdd(&accB[lyw * kAccWin + lxw], pack_candidate(e.d));
+        } else {
+          atomicAdd(&ga[(size_t)(row * S + col) * 2], 1ull);
+          if (near) atomicAdd(&ga[(size_t)(row * S + col) * 2 + 1], pack_candidate(e.d));
+        }
       }
     }
   }
@@ -612,8 +624,10 @@ raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, unsigned long
   for (int i = t; i < wh * kAccWin; i += 256) {
     const int lyw = i / kAccWin, lxw = i % kAccWin;
     if (lxw >= ww) continue;
-    const unsigned long long v = acc[lyw * kAccWin + lxw];
-    if (v) atomicAdd(&ga[(wy0 + lyw) * S + wx0 + lxw], v);
+    const unsigned long long va = accA[lyw * kAccWin + lxw], vb = accB[lyw * kAccWin + lxw];
+    const size_t gi = (size_t)((wy0 + lyw) * S + wx0 + lxw) * 2;
+    if (va) atomicAdd(&ga[gi], va);
+    if (vb) atomicAdd(&ga[gi + 1], vb);
   }
 }
 
@@ -621,8 +635,10 @@ raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, unsigned long
 // global queue (one atomic per block) and finished by raster_select_kernel.
 __global__ void __launch_bounds__(256)
 raster_resolve_kernel(int S, int M, int window, float w_sil, const unsigned long long* __restrict__ gacc,
-                      const float* __restrict__ tsil, float* __restrict__ sil_out, float2* __restrict__ gz,
-                      float* __restrict__ blk_loss, int* __restrict__ qcount, int* __restrict__ queue) {
+                      const float* __restrict__ tsil, float* __restrict__ sil_out,
+                      float2* __restrict__ gz /*in: .y = previous threshold*/,
+                      float* __restrict__ blk_loss, int* __restrict__ qcount, int* __restrict__ queue,
+                      int* __restrict__ stats /*developer counters or null*/) {
   __shared__ int qn, qbase;
   __shared__ float red[16];
   const int n = blockIdx.y;
@@ -634,14 +650,26 @@ raster_resolve_kernel(int S, int M, int window, float w_sil, const unsigned long
   if (t == 0) qn = 0;
   __syncthreads();
   int c = 0;
-  float alpha = 1.0f;
+  float alpha = 1.0f, zthr = __int_as_float(0x7f800000);
+  bool settled = true;
   if (inimg) {
-    const unsigned long long v = gacc[((size_t)n * S + row) * S + col];
-    c = (int)(v >> kCountShift);
-    if (c > 0 && c <= kFacesPerPixel)
-      alpha = (float)exp2(-(double)(v & ((1ull << kCountShift) - 1ull)) * (1.0 / (double)kLogFix));
+    const size_t pi = ((size_t)n * S + row) * S + col;
+    c = (int)gacc[pi * 2];
+    if (c > 0) {
+      const unsigned long long vb = gacc[pi * 2 + 1];
+      const int cn = (int)(vb >> kCountShift);
+      const bool all_near = (cn == c) && (c <= kFacesPerPixel);
+      const bool k_near = (c > kFacesPerPixel) && (cn == kFacesPerPixel);
+      if (stats && c > kFacesPerPixel) { atomicAdd(&stats[1], 1); if (k_near) atomicAdd(&stats[2], 1); }
+      if (all_near || k_near) {
+        alpha = (float)exp2(-(double)(vb & ((1ull << kCountShift) - 1ull)) * (1.0 / (double)kLogFix));
+        if (k_near) zthr = gz[pi].y;        // the threshold still separates exactly K candidates
+      } else {
+        settled = false;
+      }
+    }
   }
-  const bool queued = c > kFacesPerPixel;
+  const bool queued = !settled;
   int slot = 0;
   if (queued) slot = atomicAdd(&qn, 1);
   __syncthreads();
@@ -661,7 +689,7 @@ raster_resolve_kernel(int S, int M, int window, float w_sil, const unsigned long
       const float sgn = (diff > 0.f) ? 1.0f : ((diff < 0.f) ? -1.0f : 0.0f);
       gx = -(w_sil / ((float)Bn * (float)S * (float)S)) * sgn * alpha * (1.0f / kSigma);
     }
-    if (gz) gz[pi] = make_float2(gx, __int_as_float(0x7f800000));
+    gz[pi] = make_float2(gx, zthr);
   }
   if (blk_loss) {
     l = block_sum(l, red);
@@ -677,19 +705,21 @@ constexpr int kCandCap = 1024;            // candidates per pixel kept in LDS; b
 constexpr int kHitCap = 1024;             // union boxes containing a pixel kept in LDS (aliases the candidate buffer)
 constexpr int kCoverCap = 2048;           // faces whose box covers the pixel, kept in LDS (u16 ids)
 
-__global__ void __launch_bounds__(256)
+constexpr int kSelWaves = 2;              // waves per select block: 13 KB of LDS per wave -> 6 blocks (12 waves) per CU
+
+__global__ void __launch_bounds__(64 * kSelWaves)
 raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4* __restrict__ frec,
                      const int4* __restrict__ brect, const int2* __restrict__ fbox, const int* __restrict__ qcount,
-                     const int* __restrict__ queue, const float* __restrict__ tsil, float* __restrict__ sil_out,
-                     float2* __restrict__ gz,
+                     const int* __restrict__ queue, const float* __restrict__ tsil,
+                     float* __restrict__ sil_out, float2* __restrict__ gz,
                      float* __restrict__ qloss /*[gridDim.x]: weighted |sil - target| summed per block, or null*/, int dbg) {
-  __shared__ unsigned hist[4][256];
-  __shared__ float2 cand[4][kCandCap];
-  __shared__ unsigned short fids[4][kCoverCap];
+  __shared__ unsigned hist[kSelWaves][256];
+  __shared__ float2 cand[kSelWaves][kCandCap];
+  __shared__ unsigned short fids[kSelWaves][kCoverCap];
   // the union-box hit list is consumed (stage A) before the first candidate is written (stage B): share storage
   int (*hits)[2 * kCandCap] = reinterpret_cast<int (*)[2 * kCandCap]>(&cand[0][0]);
   static_assert(kHitCap <= 2 * kCandCap, "hit list must fit in the candidate buffer");
-  __shared__ float wloss[4];
+  __shared__ float wloss[kSelWaves];
   float lacc = 0.f;
   constexpr int K = kFacesPerPixel;
   constexpr int RC = kCandCap / 64;
@@ -699,7 +729,7 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
   const int nrect = (F + kRectFaces - 1) / kRectFaces;
   const float inv_s = 1.0f / (float)S;
   const int npix = S * S;
-  for (int qi = blockIdx.x * 4 + w; qi < nq; qi += gridDim.x * 4) {
+  for (int qi = blockIdx.x * kSelWaves + w; qi < nq; qi += gridDim.x * kSelWaves) {
     const int gp = queue[qi];
     const int n = gp / npix, pix = gp % npix;
     const int pcol = pix % S, prow = pix / S;
@@ -756,7 +786,7 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
     const bool compact = (nh <= kHitCap) && (ncov <= kCoverCap) && (F <= 65536);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // visit every candidate of the pixel in face order: fn(valid, pz, d) is called wave-wide
+    // visit every candidate of the pixel in face order: fn(valid, pz, d, face) is called wave-wide
     auto scan_candidates = [&](auto&& fn) {
       if (compact) {
         float4 pa, pb, pc;
@@ -772,6 +802,7 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
         for (int j = 0; j < ncov; j += 64) {
           const float4 a = pa, b = pb, c = pc;
           const bool live = plive;
+          const int cur_ff = live ? (int)fids[w][j + lane] : 0;
           if (j + 64 < ncov) prefetch(j + 64);
           bool ok = false;
           PixEval e; e.pz = 0.f; e.d = 0.f;
@@ -780,7 +811,7 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
             make_face_rec(a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, r);
             ok = face_pixel_eval(r, ppx, ppy, e);
           }
-          fn(ok, e.pz, e.d);
+          fn(ok, e.pz, e.d, cur_ff);
         }
       } else {                      // pathological: walk every face
         for (int f0 = 0; f0 < F; f0 += 64) {
@@ -792,12 +823,12 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
             load_face_rec(fr + (size_t)ff * 3, r, box);
             if (box_contains(box, pcol, prow)) ok = face_pixel_eval(r, ppx, ppy, e);
           }
-          fn(ok, e.pz, e.d);
+          fn(ok, e.pz, e.d, ff);
         }
       }
     };
     int nc = 0;
-    scan_candidates([&](bool ok, float pz, float d) {
+    scan_candidates([&](bool ok, float pz, float d, int ff) {
       const unsigned long long bal = __ballot(ok);
       if (ok) {
         const int pos = nc + __popcll(bal & ((1ull << lane) - 1ull));
@@ -809,9 +840,9 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
     __builtin_amdgcn_wave_barrier();
     if (dbg & 4) continue;
     const bool cached = nc <= kCandCap;
-    unsigned prefix = 0u;
+    unsigned prefix = (nc <= K) ? 0xffffffffu : 0u;      // at most K candidates: keep them all, threshold +inf
     int need = K;
-    for (int pass = 0; pass < 4; ++pass) {
+    for (int pass = 0; pass < ((nc <= K) ? 0 : 4); ++pass) {
       const int shift = 24 - 8 * pass;
 #pragma unroll
       for (int i = 0; i < 4; ++i) hist[w][lane * 4 + i] = 0u;
@@ -827,8 +858,8 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
           }
         }
       } else {
-        scan_candidates([&](bool ok, float pz, float d) {
-          (void)d;
+        scan_candidates([&](bool ok, float pz, float d, int ff) {
+          (void)d; (void)ff;
           const unsigned kk = orderable(pz);
           const bool in = ok && ((pass == 0) || ((kk >> (shift + 8)) == (prefix >> (shift + 8))));
           if (in) atomicAdd(&hist[w][(kk >> shift) & 255u], 1u);
@@ -872,9 +903,30 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
         if (j < nc) { const float2 ev = cand[w][j]; if (orderable(ev.x) <= prefix) a *= ev.y; }
       }
     } else {
-      scan_candidates([&](bool ok, float pz, float d) { if (ok && orderable(pz) <= prefix) a *= one_minus_prob(d); });
+      scan_candidates([&](bool ok, float pz, float d, int ff) { (void)ff; if (ok && orderable(pz) <= prefix) a *= one_minus_prob(d); });
     }
     a = wave_prod(a);
+    // threshold stored for the backward pass and for next evaluation's shortcut: midway between the K-th and the
+    // (K+1)-th nearest depth, so that small pose changes keep exactly K candidates below it
+    unsigned nextk = 0xffffffffu;
+    if (cached) {
+#pragma unroll 4
+      for (int i = 0; i < RC; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nc) { const unsigned kk = orderable(cand[w][j].x); if (kk > prefix) nextk = min(nextk, kk); }
+      }
+    } else {
+      scan_candidates([&](bool ok, float pz, float d, int ff) { (void)d; (void)ff; const unsigned kk = orderable(pz); if (ok && kk > prefix) nextk = min(nextk, kk); });
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nextk = min(nextk, (unsigned)__shfl_xor((int)nextk, o, 64));
+    const float zk = (nc <= K) ? __int_as_float(0x7f800000) : from_orderable(prefix);
+    float zmid = zk;
+    if (nc > K && nextk != 0xffffffffu) {
+      const float zn = from_orderable(nextk);
+      zmid = 0.5f * (zk + zn);
+      if (!(zmid >= zk && zmid < zn)) zmid = zk;
+    }
     if (lane == 0) {
       const size_t pi = (size_t)gp;
       const float sil = 1.0f - a;
@@ -888,7 +940,7 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
         const float sgn = (diff > 0.f) ? 1.0f : ((diff < 0.f) ? -1.0f : 0.0f);
         gx = -wn * sgn * a * (1.0f / kSigma);
       }
-      if (gz) gz[pi] = make_float2(gx, from_orderable(prefix));
+      gz[pi] = make_float2(gx, zmid);
       lacc += l;
     }
     __builtin_amdgcn_wave_barrier();
@@ -896,7 +948,7 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
   if (qloss) {
     if (lane == 0) wloss[w] = lacc;
     __syncthreads();
-    if (t == 0) qloss[blockIdx.x] = (wloss[0] + wloss[1]) + (wloss[2] + wloss[3]);
+    if (t == 0) { float tot = 0.f; for (int i = 0; i < kSelWaves; ++i) tot += wloss[i]; qloss[blockIdx.x] = tot; }
   }
 }
 
