@@ -69,31 +69,40 @@ def build_problem(engine, torch, scene):
 
 
 def cpu_baseline(md, pose_prior, shape_prior, target_joints, vis, target_sil, stage_weights, w_temp):
-    """Times the oracle (CPU port of the same maths, torch float32) on a bounded sample: 1 frame x 1 iteration
-    of a stage-2-type epoch (forward + backward + Adam), extrapolated to 64 frames.  torch intra-op threads are
-    capped at 16: the oracle's tensors are small and more threads only add contention."""
+    """Times the oracle (CPU port of the same maths: torch float32, pair-list rasteriser, autograd backward, Adam) on a
+    bounded sample of the same workload: one stage-2-type iteration over the first `nf` of the 64 frames, where nf is
+    chosen from a 1-frame probe so that the sample costs roughly 10-15 s; extrapolated linearly to 64 frames.
+    torch intra-op threads are capped at 16 (the oracle's tensors are small; more threads only add contention)."""
     import torch
     from oracle import smal_oracle as so
+    from smalify_amd import model_io
     ncores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(ncores)
-    nf = 1
     om = so.OracleModel(md, dtype=torch.float32)
-    prob = so.FitProblem(om, IMAGE_SIZE, target_joints[:nf], vis[:nf], target_sil[:nf], pose_prior[0], pose_prior[1],
-                         pose_prior[2], shape_prior[0], shape_prior[1], nf, True, dtype=torch.float32)
-    from smalify_amd import model_io
-    params = dict(betas=torch.from_numpy(shape_prior[1][:20].copy()), log_beta_scales=torch.from_numpy(shape_prior[1][20:26].copy()),
-                  global_rotation=torch.from_numpy(np.tile(model_io.initial_global_rotation(), (nf, 1))).float(),
-                  trans=torch.zeros(nf, 3), joint_rotations=torch.zeros(nf, 34, 3))
-    opt = so.Adam(so.PARAM_ORDER, lr=5e-4)
-    t0 = time.perf_counter()
-    total, sums, grads = so.loss_and_grads(prob, params, stage_weights, w_temp, so.PARAM_ORDER)
-    opt.step(params, grads)
-    dt = time.perf_counter() - t0
-    assert sums.get("sil_reproj", 0.0) > 0.0, "silhouette term missing from the CPU baseline sample"
+
+    def one_iteration(nf):
+        prob = so.FitProblem(om, IMAGE_SIZE, target_joints[:nf], vis[:nf], target_sil[:nf], pose_prior[0], pose_prior[1],
+                             pose_prior[2], shape_prior[0], shape_prior[1], min(WINDOW, nf), True, dtype=torch.float32)
+        params = dict(betas=torch.from_numpy(shape_prior[1][:20].copy()),
+                      log_beta_scales=torch.from_numpy(shape_prior[1][20:26].copy()),
+                      global_rotation=torch.from_numpy(np.tile(model_io.initial_global_rotation(), (nf, 1))).float(),
+                      trans=torch.zeros(nf, 3), joint_rotations=torch.zeros(nf, 34, 3))
+        opt = so.Adam(so.PARAM_ORDER, lr=5e-4)
+        t0 = time.perf_counter()
+        total, sums, grads = so.loss_and_grads(prob, params, stage_weights, w_temp, so.PARAM_ORDER)
+        opt.step(params, grads)
+        dt = time.perf_counter() - t0
+        assert sums.get("sil_reproj", 0.0) > 0.0, "silhouette term missing from the CPU baseline sample"
+        return dt
+
+    t1 = one_iteration(1)
+    nf = int(max(1, min(NUM_FRAMES, 12.0 / max(t1, 1e-3))))
+    dt = one_iteration(nf) if nf > 1 else t1
     per_iter_64 = dt * (NUM_FRAMES / nf)
     return {"value": 1.0 / per_iter_64, "unit": "iterations/s", "cores": ncores, "kind": "port",
             "sample": "oracle (torch CPU float32 restatement, pair-list rasteriser) on %d of 64 frames, 1 stage-2-type "
-                      "iteration incl. backward + Adam: %.2f s (sil term %.3f); extrapolated x%d" % (nf, dt, sums["sil_reproj"], NUM_FRAMES // nf)}
+                      "iteration incl. backward + Adam: %.2f s (1-frame probe %.2f s); extrapolated x%.2f"
+                      % (nf, dt, t1, NUM_FRAMES / nf)}
 
 
 def main():
@@ -182,6 +191,17 @@ def main():
         dom_name = max(cand, key=cand.get) if cand else None
         dom = cand.get(dom_name) if dom_name else None
         achieved = algo_bytes / (dom * 1e-3) / 1e9 if dom else None
+        # HBM traffic per launch of that kernel from the rocprofv3 PMC passes committed under profiles/
+        # (tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate runs; KiB, raw -- on gfx950 FETCH_SIZE
+        # under-reports wide coalesced reads by 2x, MI355X_MICROARCH.md, so this is a lower bound)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")))
+            kname = "smalfit::" + {"raster_sweep": "raster_sweep_kernel", "raster_select": "raster_select_kernel",
+                                   "raster_resolve": "raster_resolve_kernel", "raster_bwd": "raster_bwd_kernel"}[dom_name]
+            traffic = 1024.0 * (pmc["fetch"].get(kname, {}).get("avg_per_row", 0.0) + pmc["write"].get(kname, {}).get("avg_per_row", 0.0))
+        except Exception:
+            traffic = None
         out = {
             "metric": "fitter iterations/sec", "value": args.steps / elapsed, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -191,7 +211,7 @@ def main():
                                    % (NUM_FRAMES, S, S, WINDOW, args.steps, sched, args.scene),
                        "frames": NUM_FRAMES, "image_size": S, "window": WINDOW, "parallelism": "frames/%d" % world},
             "roofline": {"bound": "hbm", "kernel": {"raster_sweep": "raster_sweep_kernel", "raster_select": "raster_select_kernel", "raster_resolve": "raster_resolve_kernel", "raster_bwd": "raster_bwd_kernel"}.get(dom_name), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": dom},
             "section_ms": sec_ms, "final_losses": dict(zip(eng.LOSS_NAMES, final_losses)), "status_bits": status,
         }
