@@ -58,6 +58,10 @@ int smalfit_engine_create(smalfit_model* model, int max_frames, int image_size, 
 void smalfit_engine_destroy(smalfit_engine* engine);
 /* synchronises `stream`, returns and clears the sticky status bits (SMALFIT_STATUS_*) */
 int smalfit_engine_status(smalfit_engine* engine, void* stream, int* status_bits);
+/* The rasteriser keeps, per pixel, the depth bounds of its last exact K-nearest selection and re-proves them from
+ * counts at every evaluation (results never depend on that state, only the time does).  This call forgets the
+ * bounds, e.g. before fitting an unrelated sequence with the same engine.  No counterpart in the reference. */
+int smalfit_engine_reset_raster_cache(smalfit_engine* engine, void* stream);
 
 /* optional: time sections of smalfit_fit_eval with HIP events recorded on the caller's stream.
  * profile_begin arms up to max_evals evaluations; profile_end synchronises `stream`, and returns the summed

@@ -11,7 +11,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsmalfit.so")
+LIB_PATH = os.environ.get("SMALFIT_LIB") or os.path.join(_HERE, "libsmalfit.so")   # override: development builds
 CSRC = os.path.join(_HERE, "csrc")
 
 _lib = None
@@ -53,6 +53,7 @@ SIGNATURES = {
     "smalfit_engine_create": (_I, [_VP, _I, _I, C.POINTER(_VP)]),
     "smalfit_engine_destroy": (None, [_VP]),
     "smalfit_engine_status": (_I, [_VP, _VP, c_int_p]),
+    "smalfit_engine_reset_raster_cache": (_I, [_VP, _VP]),
     "smalfit_engine_profile_begin": (_I, [_VP, _I]),
     "smalfit_engine_profile_end": (_I, [_VP, _VP, _VP, _VP]),
     "smalfit_engine_set_pose_prior": (_I, [_VP, _VP, _VP, _VP]),

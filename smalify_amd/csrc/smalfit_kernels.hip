@@ -477,6 +477,9 @@ constexpr int kSweepFaces = 128;          // faces per sweep block
 constexpr int kAccWin = 48;               // LDS accumulator window edge (pixels); outside: global atomics
 constexpr int kCountShift = 50;
 constexpr float kLogFix = 268435456.0f;   // 2^28
+constexpr int kBandCap = 32;              // per-pixel list of candidates between the two cached depth bounds
+constexpr int kBandFill = 24;             // the select kernel sizes the band to hold at most this many entries
+constexpr float kBandHalf = 8.0f;         // initial half-width of the band, in mean depth gaps of the K nearest
 
 __device__ __forceinline__ unsigned orderable(float f) {
   const unsigned u = __float_as_uint(f);
@@ -557,22 +560,23 @@ __device__ __forceinline__ bool load_face_rec(const float4* __restrict__ fr, Fac
   return make_face_rec(a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, r);
 }
 
-// 5b: sweep.  Two accumulators per pixel: A = number of candidates, B = packed (count, log sum) over the
-// candidates not farther than the pixel's depth threshold of the previous evaluation (gz.y; +inf for pixels that had
-// at most K candidates).  If B counts all candidates (and there are at most K), or exactly K of more than K, B's
-// set IS the K nearest (everything else is farther than the threshold): no selection needed this time.
+// 5b: sweep.  Each pixel carries two cached depth bounds lo <= hi from the last exact selection (zband; +inf
+// while the pixel never had more than K candidates).  Candidates not farther than lo are accumulated into ONE packed
+// integer (count << 50 | log sum); candidates in (lo, hi] are appended to the pixel's short band list; farther ones
+// are dropped.  raster_resolve_kernel proves from the counts that the K nearest are {<= lo} + the nearest few of the
+// band, or sends the pixel to the exact selection.
 __global__ void __launch_bounds__(256)
-raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, const float2* __restrict__ gz_prev,
-                    unsigned long long* __restrict__ gacc /*[M][S*S][2]*/) {
+raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, const float2* __restrict__ zband,
+                    unsigned long long* __restrict__ gacc /*[M][S*S]*/, unsigned* __restrict__ bcnt /*[M][S*S]*/,
+                    float2* __restrict__ blist /*[M][S*S][kBandCap]*/) {
   __shared__ __attribute__((aligned(16))) FaceRec recs[kSweepFaces];
   __shared__ int2 boxes[kSweepFaces];
-  __shared__ unsigned long long accB[kAccWin * kAccWin];   // near candidates: count << 50 | log sum
-  __shared__ unsigned accA[kAccWin * kAccWin];             // all candidates: count
+  __shared__ unsigned long long acc[kAccWin * kAccWin];   // near candidates: count << 50 | log sum
   __shared__ int rect[4];
   const int n = blockIdx.y, t = threadIdx.x;
   const int f0 = blockIdx.x * kSweepFaces;
   if (t < 4) rect[t] = (t & 1) ? -1 : 0x7fff;          // x0, x1, y0, y1
-  for (int i = t; i < kAccWin * kAccWin; i += 256) { accA[i] = 0u; accB[i] = 0ull; }
+  for (int i = t; i < kAccWin * kAccWin; i += 256) acc[i] = 0ull;
   __syncthreads();
   if (t < kSweepFaces) {
     int2 box = make_int2(1, 1);
@@ -590,8 +594,9 @@ raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, const float2*
   __syncthreads();
   if (rect[1] < rect[0]) return;                        // no face of this block is on screen
   const int wx0 = rect[0], wy0 = rect[2];
-  unsigned long long* ga = gacc + (size_t)n * S * S * 2;
-  const float2* gzp = gz_prev + (size_t)n * S * S;
+  const size_t fbase = (size_t)n * S * S;
+  unsigned long long* ga = gacc + fbase;
+  const float2* zbp = zband + fbase;
   const int sub = t & 15, lx = sub & 3, ly = sub >> 2, grp = t >> 4;
   const float inv_s = 1.0f / (float)S;
   for (int step = 0; step < kSweepFaces / 16; ++step) {
@@ -604,17 +609,20 @@ raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, const float2*
       for (int cx = c0; cx <= c1; cx += 4) {
         const int col = cx + lx;
         if (row > r1 || col > c1) continue;
-        const float bound = gzp[row * S + col].y;
+        const float2 zb = zbp[row * S + col];
+        const float ppx = pix_to_ndc(col, inv_s), ppy = pix_to_ndc(row, inv_s);
+        const float pz0 = face_pixel_depth(recs[k], ppx, ppy);
+        if (!(pz0 <= zb.y)) continue;                  // beyond the pixel's far bound: dropped whatever its distance
         PixEval e;
-        if (!face_pixel_eval(recs[k], pix_to_ndc(col, inv_s), pix_to_ndc(row, inv_s), e)) continue;
-        const bool near = e.pz <= bound;
-        const int lxw = col - wx0, lyw = row - wy0;
-        if (lxw < kAccWin && lyw < kAccWin) {
-          atomicAdd(&accA[lyw * kAccWin + lxw], 1u);
-          if (near) atomicAdd(&accB[lyw * kAccWin + lxw], pack_candidate(e.d));
-        } else {
-          atomicAdd(&ga[(size_t)(row * S + col) * 2], 1ull);
-          if (near) atomicAdd(&ga[(size_t)(row * S + col) * 2 + 1], pack_candidate(e.d));
+        if (!face_pixel_eval(recs[k], ppx, ppy, e)) continue;
+        if (e.pz <= zb.x) {
+          const int lxw = col - wx0, lyw = row - wy0;
+          if (lxw < kAccWin && lyw < kAccWin) atomicAdd(&acc[lyw * kAccWin + lxw], pack_candidate(e.d));
+          else atomicAdd(&ga[row * S + col], pack_candidate(e.d));
+        } else if (e.pz <= zb.y) {
+          const size_t pi = fbase + (size_t)(row * S + col);
+          const unsigned slot = atomicAdd(&bcnt[pi], 1u);
+          if (slot < (unsigned)kBandCap) blist[pi * kBandCap + slot] = make_float2(e.pz, e.d);
         }
       }
     }
@@ -624,76 +632,153 @@ raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, const float2*
   for (int i = t; i < wh * kAccWin; i += 256) {
     const int lyw = i / kAccWin, lxw = i % kAccWin;
     if (lxw >= ww) continue;
-    const unsigned long long va = accA[lyw * kAccWin + lxw], vb = accB[lyw * kAccWin + lxw];
-    const size_t gi = (size_t)((wy0 + lyw) * S + wx0 + lxw) * 2;
-    if (va) atomicAdd(&ga[gi], va);
-    if (vb) atomicAdd(&ga[gi + 1], vb);
+    const unsigned long long v = acc[lyw * kAccWin + lxw];
+    if (v) atomicAdd(&ga[(wy0 + lyw) * S + wx0 + lxw], v);
   }
 }
 
-// 5c: resolve.  Thread per pixel: alpha = 2^-sum.  Pixels with more than K candidates are appended to a
-// global queue (one atomic per block) and finished by raster_select_kernel.
+// 5c: resolve.  With c = #candidates <= lo and b = #band entries of a pixel, the K nearest are known exactly when
+// (no bounds yet: c <= K)  or  (c <= K <= c + b: {<= lo} plus the K - c nearest band entries)  or  (hi = +inf and
+// c + b < K: everything).  Otherwise -- more than K below lo, a band overflow, an unknown number beyond hi, or a
+// depth tie at the cut -- raster_select_kernel redoes the pixel from scratch and refreshes its bounds.
+// raster_resolve_kernel is thread-per-pixel: it finishes the pixels that need no sorting and appends the others to
+// the band queue or the select queue (one global atomic per block and queue).
 __global__ void __launch_bounds__(256)
 raster_resolve_kernel(int S, int M, int window, float w_sil, const unsigned long long* __restrict__ gacc,
+                      const unsigned* __restrict__ bcnt, const float2* __restrict__ zband,
                       const float* __restrict__ tsil, float* __restrict__ sil_out,
-                      float2* __restrict__ gz /*in: .y = previous threshold*/,
-                      float* __restrict__ blk_loss, int* __restrict__ qcount, int* __restrict__ queue,
-                      int* __restrict__ stats /*developer counters or null*/) {
-  __shared__ int qn, qbase;
+                      float2* __restrict__ gz, float* __restrict__ blk_loss, int* __restrict__ qcount /*[0] select, [1] band*/,
+                      int* __restrict__ queue, int* __restrict__ bqueue, int* __restrict__ stats /*developer counters or null*/) {
+  __shared__ int qn[2], qbase[2];
   __shared__ float red[16];
+  constexpr int K = kFacesPerPixel;
+  constexpr unsigned long long kSumMask = (1ull << kCountShift) - 1ull;
+  const float kInf = __int_as_float(0x7f800000);
   const int n = blockIdx.y;
   const int TX = (S + 15) / 16;
   const int tx = blockIdx.x % TX, ty = blockIdx.x / TX;
   const int t = threadIdx.x;
   const int col = tx * 16 + (t & 15), row = ty * 16 + (t >> 4);
   const bool inimg = (col < S) && (row < S);
-  if (t == 0) qn = 0;
+  const size_t pi = ((size_t)n * S + row) * S + col;
+  if (t < 2) qn[t] = 0;
   __syncthreads();
-  int c = 0;
-  float alpha = 1.0f, zthr = __int_as_float(0x7f800000);
-  bool settled = true;
-  if (inimg) {
-    const size_t pi = ((size_t)n * S + row) * S + col;
-    c = (int)gacc[pi * 2];
-    if (c > 0) {
-      const unsigned long long vb = gacc[pi * 2 + 1];
-      const int cn = (int)(vb >> kCountShift);
-      const bool all_near = (cn == c) && (c <= kFacesPerPixel);
-      const bool k_near = (c > kFacesPerPixel) && (cn == kFacesPerPixel);
-      if (stats && c > kFacesPerPixel) { atomicAdd(&stats[1], 1); if (k_near) atomicAdd(&stats[2], 1); }
-      if (all_near || k_near) {
-        alpha = (float)exp2(-(double)(vb & ((1ull << kCountShift) - 1ull)) * (1.0 / (double)kLogFix));
-        if (k_near) zthr = gz[pi].y;        // the threshold still separates exactly K candidates
-      } else {
-        settled = false;
-      }
-    }
-  }
-  const bool queued = !settled;
-  int slot = 0;
-  if (queued) slot = atomicAdd(&qn, 1);
-  __syncthreads();
-  if (t == 0) qbase = qn > 0 ? atomicAdd(qcount, qn) : 0;
-  __syncthreads();
-  if (queued) queue[qbase + slot] = (n * S + row) * S + col;
+  int action = 0, slot = 0;                        // 0: finished from the sum alone, 1: select queue, 2: band queue
   float l = 0.f;
-  if (inimg && !queued) {
-    const size_t pi = ((size_t)n * S + row) * S + col;
-    const float sil = 1.0f - alpha;
-    if (sil_out) sil_out[pi] = sil;
-    float gx = 0.f;
-    if (tsil) {
-      const float diff = sil - tsil[pi];
-      l = fabsf(diff);
-      const int Bn = frame_window_size(n, M, window);
-      const float sgn = (diff > 0.f) ? 1.0f : ((diff < 0.f) ? -1.0f : 0.0f);
-      gx = -(w_sil / ((float)Bn * (float)S * (float)S)) * sgn * alpha * (1.0f / kSigma);
+  if (inimg) {
+    const unsigned long long vb = gacc[pi];
+    const int c = (int)(vb >> kCountShift);
+    const int b = (int)bcnt[pi];
+    const float2 zb = zband[pi];
+    const int need = K - c;
+    float zthr = kInf;
+    if (!(zb.x < kInf)) action = (c <= K) ? 0 : 1;
+    else if (need < 0 || b > kBandCap) action = 1;
+    else if (need == 0) zthr = zb.x;                              // exactly K at or below lo
+    else if (need > b) action = (zb.y < kInf) ? 1 : (b == 0 ? 0 : 2);   // hi = +inf: fewer than K candidates in all
+    else action = 2;
+    if (stats && zb.x < kInf) { atomicAdd(&stats[1], 1); if (action != 1) { atomicAdd(&stats[2], 1); atomicAdd(&stats[3], b); } }
+    if (action == 0) {
+      const float alpha = (c > 0) ? (float)exp2(-(double)(vb & kSumMask) * (1.0 / (double)kLogFix)) : 1.0f;
+      const float sil = 1.0f - alpha;
+      if (sil_out) sil_out[pi] = sil;
+      float gx = 0.f;
+      if (tsil) {
+        const float diff = sil - tsil[pi];
+        l = fabsf(diff);
+        const float sgn = (diff > 0.f) ? 1.0f : ((diff < 0.f) ? -1.0f : 0.0f);
+        gx = -(w_sil / ((float)frame_window_size(n, M, window) * (float)S * (float)S)) * sgn * alpha * (1.0f / kSigma);
+      }
+      gz[pi] = make_float2(gx, zthr);
+    } else {
+      slot = atomicAdd(&qn[action - 1], 1);
     }
-    gz[pi] = make_float2(gx, zthr);
   }
+  __syncthreads();
+  if (t < 2) qbase[t] = qn[t] > 0 ? atomicAdd(&qcount[t], qn[t]) : 0;
+  __syncthreads();
+  if (action == 1) queue[qbase[0] + slot] = (int)pi;
+  else if (action == 2) bqueue[qbase[1] + slot] = (int)pi;
   if (blk_loss) {
     l = block_sum(l, red);
     if (t == 0) blk_loss[(size_t)n * gridDim.x + blockIdx.x] = l;
+  }
+}
+
+// 5c': band.  Persistent grid, one half-wave per queued pixel, lane per band entry (one coalesced 256-byte read):
+// rank by counting against an LDS broadcast of the 32 depths, include the K - c nearest, check for a tie at the cut.
+constexpr int kBandBlocks = 1024;
+__global__ void __launch_bounds__(256)
+raster_band_kernel(int S, int M, int window, float w_sil, const unsigned long long* __restrict__ gacc,
+                   const unsigned* __restrict__ bcnt, const float2* __restrict__ blist,
+                   const float* __restrict__ tsil, float* __restrict__ sil_out, float2* __restrict__ gz,
+                   int* __restrict__ qcount, int* __restrict__ queue, const int* __restrict__ bqueue,
+                   float* __restrict__ bloss /*[gridDim.x]: weighted |sil - target| per block, or null*/) {
+  static_assert(kBandCap == 32, "one band entry per lane of a half-wave");
+  __shared__ __attribute__((aligned(16))) float zs[8][32];
+  __shared__ float red[16];
+  constexpr int K = kFacesPerPixel;
+  constexpr unsigned long long kSumMask = (1ull << kCountShift) - 1ull;
+  const float kInf = __int_as_float(0x7f800000);
+  const int t = threadIdx.x, hw = t >> 5, hl = t & 31;
+  const int nb = qcount[1];
+  const int npix = S * S;
+  float lacc = 0.f;
+  for (int j = blockIdx.x * 8 + hw; j < nb; j += gridDim.x * 8) {
+    const int gp = bqueue[j];
+    const size_t pi = (size_t)gp;
+    const unsigned long long vb = gacc[pi];
+    const int b = (int)bcnt[pi];
+    const float ts = tsil ? tsil[pi] : 0.f;
+    float2 v = make_float2(kInf, 0.f);
+    if (hl < b) v = blist[pi * kBandCap + hl];
+    const int need = min(K - (int)(vb >> kCountShift), b);
+    zs[hw][hl] = v.x;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int rank = 0;
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) {
+      const float4 q = *reinterpret_cast<const float4*>(&zs[hw][k4 * 4]);
+      rank += (q.x < v.x) + (q.y < v.x) + (q.z < v.x) + (q.w < v.x);
+    }
+    const bool in = (hl < b) && (rank < need);
+    const unsigned long long pv = in ? (pack_candidate(v.y) & kSumMask) : 0ull;
+    int s_lo = (int)(pv & 0x1ffffffull), s_hi = (int)(pv >> 25);
+    float zin = in ? v.x : -kInf, zout = (hl < b && !in) ? v.x : kInf;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      s_lo += __shfl_xor(s_lo, o, 32); s_hi += __shfl_xor(s_hi, o, 32);
+      zin = fmaxf(zin, __shfl_xor(zin, o, 32)); zout = fminf(zout, __shfl_xor(zout, o, 32));
+    }
+    // ranks ignore ties: with a tie at the cut the number of entries <= zin is not `need`; let the selection decide
+    const unsigned long long bal = __ballot((hl < b) && (v.x <= zin));
+    const int taken = __popc((unsigned)(bal >> (32 * (hw & 1))));
+    if (hl == 0) {
+      if (taken == need && zin < zout) {
+        const unsigned long long sum = (vb & kSumMask) + ((unsigned long long)s_hi << 25) + (unsigned long long)s_lo;
+        const float alpha = (float)exp2(-(double)sum * (1.0 / (double)kLogFix));
+        const float sil = 1.0f - alpha;
+        if (sil_out) sil_out[pi] = sil;
+        float gx = 0.f;
+        if (tsil) {
+          const int n = gp / npix;
+          const float wn = w_sil / ((float)frame_window_size(n, M, window) * (float)S * (float)S);
+          const float diff = sil - ts;
+          lacc += fabsf(diff) * wn;
+          const float sgn = (diff > 0.f) ? 1.0f : ((diff < 0.f) ? -1.0f : 0.0f);
+          gx = -wn * sgn * alpha * (1.0f / kSigma);
+        }
+        gz[pi] = make_float2(gx, zin);
+      } else {
+        queue[atomicAdd(&qcount[0], 1)] = gp;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (bloss) {
+    lacc = block_sum(lacc, red);
+    if (t == 0) bloss[blockIdx.x] = lacc;
   }
 }
 
@@ -711,7 +796,7 @@ __global__ void __launch_bounds__(64 * kSelWaves)
 raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4* __restrict__ frec,
                      const int4* __restrict__ brect, const int2* __restrict__ fbox, const int* __restrict__ qcount,
                      const int* __restrict__ queue, const float* __restrict__ tsil,
-                     float* __restrict__ sil_out, float2* __restrict__ gz,
+                     float* __restrict__ sil_out, float2* __restrict__ gz, float2* __restrict__ zband,
                      float* __restrict__ qloss /*[gridDim.x]: weighted |sil - target| summed per block, or null*/, int dbg) {
   __shared__ unsigned hist[kSelWaves][256];
   __shared__ float2 cand[kSelWaves][kCandCap];
@@ -906,26 +991,52 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
       scan_candidates([&](bool ok, float pz, float d, int ff) { (void)ff; if (ok && orderable(pz) <= prefix) a *= one_minus_prob(d); });
     }
     a = wave_prod(a);
-    // threshold stored for the backward pass and for next evaluation's shortcut: midway between the K-th and the
-    // (K+1)-th nearest depth, so that small pose changes keep exactly K candidates below it
-    unsigned nextk = 0xffffffffu;
+    // depth of the K-th nearest, the nearest beyond it, and the nearest of all
+    unsigned nextk = 0xffffffffu, mink = 0xffffffffu;
     if (cached) {
 #pragma unroll 4
       for (int i = 0; i < RC; ++i) {
         const int j = lane + 64 * i;
-        if (j < nc) { const unsigned kk = orderable(cand[w][j].x); if (kk > prefix) nextk = min(nextk, kk); }
+        if (j < nc) { const unsigned kk = orderable(cand[w][j].x); mink = min(mink, kk); if (kk > prefix) nextk = min(nextk, kk); }
       }
     } else {
-      scan_candidates([&](bool ok, float pz, float d, int ff) { (void)d; (void)ff; const unsigned kk = orderable(pz); if (ok && kk > prefix) nextk = min(nextk, kk); });
+      scan_candidates([&](bool ok, float pz, float d, int ff) { (void)d; (void)ff; const unsigned kk = orderable(pz); if (ok) { mink = min(mink, kk); if (kk > prefix) nextk = min(nextk, kk); } });
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) nextk = min(nextk, (unsigned)__shfl_xor((int)nextk, o, 64));
-    const float zk = (nc <= K) ? __int_as_float(0x7f800000) : from_orderable(prefix);
+    for (int o = 32; o > 0; o >>= 1) {
+      nextk = min(nextk, (unsigned)__shfl_xor((int)nextk, o, 64));
+      mink = min(mink, (unsigned)__shfl_xor((int)mink, o, 64));
+    }
+    const float kInf = __int_as_float(0x7f800000);
+    const float zk = (nc <= K) ? kInf : from_orderable(prefix);
+    // backward threshold: midway between the K-th and the (K+1)-th nearest depth
     float zmid = zk;
     if (nc > K && nextk != 0xffffffffu) {
       const float zn = from_orderable(nextk);
       zmid = 0.5f * (zk + zn);
       if (!(zmid >= zk && zmid < zn)) zmid = zk;
+    }
+    // bounds for the next evaluations: lo < K-th <= hi, the band (lo, hi] sized to at most kBandFill candidates, so
+    // that the K nearest stay provable from counts while depths drift by up to the band's half-width
+    float blo = kInf, bhi = kInf;
+    if (nc > K) {
+      blo = bhi = zmid;
+      if (cached) {
+        float delta = kBandHalf * (zk - from_orderable(mink)) * (1.0f / (float)K);
+        for (int it = 0; it < 5 && delta > 0.f; ++it) {
+          const float lo = zk - delta, hi = zk + delta;
+          int cb = 0, cfar = 0;
+#pragma unroll 4
+          for (int i = 0; i < RC; ++i) {
+            const int j = lane + 64 * i;
+            if (j < nc) { const float z = cand[w][j].x; cb += (z > lo && z <= hi) ? 1 : 0; cfar += (z > hi) ? 1 : 0; }
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) { cb += __shfl_xor(cb, o, 64); cfar += __shfl_xor(cfar, o, 64); }
+          if (cb <= kBandFill && lo < zk) { blo = lo; bhi = (cfar == 0) ? kInf : hi; break; }
+          delta *= 0.5f;
+        }
+      }
     }
     if (lane == 0) {
       const size_t pi = (size_t)gp;
@@ -941,6 +1052,7 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
         gx = -wn * sgn * a * (1.0f / kSigma);
       }
       gz[pi] = make_float2(gx, zmid);
+      zband[pi] = make_float2(blo, bhi);
       lacc += l;
     }
     __builtin_amdgcn_wave_barrier();

@@ -156,6 +156,9 @@ SMALFIT_HD bool make_face_rec(float ax, float ay, float az, float bx, float by, 
   return (fabsf(r.area) > kEps) && (zmax >= 0.0f);
 }
 
+// depth of face r at pixel centre (px, py): the same expression face_pixel_eval uses (cheap pre-test)
+SMALFIT_HD float face_pixel_depth(const FaceRec& r, float px, float py) { return face_depth(r, px - r.ax, py - r.ay); }
+
 struct PixEval {
   float d;        // signed squared distance (negative inside)
   float pz;       // interpolated view-space depth at the pixel

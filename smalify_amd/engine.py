@@ -106,6 +106,10 @@ class Engine:
 
     SECTIONS = ("lbs_fwd", "raster_sweep", "raster_select", "raster_bwd", "lbs_bwd", "raster_resolve")
 
+    def reset_raster_cache(self):
+        """Forget the rasteriser's cached per-pixel depth bounds (affects time only, never results)."""
+        check(self.lib.smalfit_engine_reset_raster_cache(self.handle, _stream()), "smalfit_engine_reset_raster_cache")
+
     def profile_begin(self, max_evals):
         check(self.lib.smalfit_engine_profile_begin(self.handle, int(max_evals)), "smalfit_engine_profile_begin")
 

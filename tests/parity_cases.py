@@ -261,3 +261,40 @@ def case_adam():
         eng.adam_step(p, dev(g), m, v, 5e-3, t)
         opt.step(po, {"x": torch.from_numpy(g).double()})
     return {"adam_rel": rel(p.cpu().numpy(), po["x"].numpy())}
+
+
+def case_cache_consistency(M=4, S=64, window=3, stage=2, z=1.45, steps=6, seed=21):
+    """Same evaluations on an engine that keeps the rasteriser's depth-bound cache and on one that resets it each time."""
+    W = np.array(cfg.OPT_WEIGHTS).T
+    weights, w_temp = W[stage][:6].copy(), float(W[stage][6])
+    e_a, prob, cur, tg = make_problem(M, S, window, seed, z=z)
+    md, om, dm = get_model()
+    e_b = eng.Engine(dm, max(M, 8), S)
+    _, pp, sp = get_engine(max(M, 8), S)
+    e_b.set_pose_prior(*pp)
+    e_b.set_shape_prior(*sp)
+    names = so.trainable_names(stage)
+
+    def ev(e, p):
+        d = {k: dev(v) for k, v in p.items()}
+        losses, grads = e.fit_eval(betas=d["betas"], log_beta_scales=d["log_beta_scales"],
+                                   global_rotation=d["global_rotation"], joint_rotations=d["joint_rotations"],
+                                   trans=d["trans"], target_joints=dev(tg["tj"]), target_visibility=dev(tg["vis"]),
+                                   target_sil=dev(tg["tsil"]), weights=weights, w_temp=w_temp, window=window, want=names)
+        return losses.cpu().numpy().astype(np.float64), {k: v.cpu().numpy().astype(np.float64) for k, v in grads.items()}
+
+    rs = np.random.RandomState(seed + 3)
+    loss_rel, grad_rel = 0.0, 0.0
+    for step in range(steps + 2):
+        if step >= 2:                      # steps 0 and 1 evaluate the same pose (fresh, then fully cached)
+            cur = {k: v.copy() for k, v in cur.items()}
+            cur["global_rotation"] += (0.004 * rs.randn(M, 3)).astype(np.float32)
+            cur["joint_rotations"] += (0.004 * rs.randn(M, 34, 3)).astype(np.float32)
+            cur["trans"] += (0.003 * rs.randn(M, 3)).astype(np.float32)
+        la, ga = ev(e_a, cur)
+        e_b.reset_raster_cache()
+        lb, gb = ev(e_b, cur)
+        loss_rel = max(loss_rel, abs(la.sum() - lb.sum()) / abs(lb.sum()))
+        for k in ga:
+            grad_rel = max(grad_rel, rel(ga[k], gb[k]))
+    return {"loss_rel_max": loss_rel, "grad_rel_max": grad_rel, "status": e_a.status() | e_b.status()}

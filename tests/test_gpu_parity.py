@@ -84,3 +84,14 @@ def test_fitter_full(stage, window):
     for k, v in m.items():
         if k.startswith("fit_grad_") and k.endswith("_rel"):
             assert v < 2e-3, (k, v, m)
+
+
+def test_raster_cache_never_changes_results():
+    """The rasteriser re-proves its cached per-pixel depth bounds from counts at every evaluation.  Engine A keeps its
+    cache while the pose drifts (stale bounds, several steps), engine B forgets it before every evaluation: losses and
+    gradients must agree to float32 summation noise, for the side view and for the head-on K-overflow view."""
+    for z in (1.45, 0.0):
+        m = pc.case_cache_consistency(z=z)
+        assert m["loss_rel_max"] < 2e-6, m
+        assert m["grad_rel_max"] < 2e-5, m
+        assert m["status"] == 0
