@@ -8,6 +8,17 @@
 
 namespace smalfit {
 
+// kinematic tree by depth: joints of one level are independent, so the chain and its adjoint take `nlev` steps
+// (10 for SMAL) instead of 34.  children lists are in DESCENDING joint order: accumulating a parent's adjoint from its
+// children in that order reproduces the summation order of a plain reverse loop over the joints.
+struct TreeLevels {
+  unsigned char nlev;
+  unsigned char lvl_off[36];     // level L owns lvl_joint[lvl_off[L] .. lvl_off[L+1])
+  unsigned char lvl_joint[35];
+  unsigned char child_off[36];   // joint j owns child_idx[child_off[j] .. child_off[j+1])
+  unsigned char child_idx[35];
+};
+
 // device-resident model constants (pointers into one allocation owned by smalfit_model)
 struct ModelDev {
   int V, Vp, F, NBall;
@@ -34,6 +45,7 @@ struct ModelDev {
   const int* vf_idx;
   const int* scale_idx;   // [105] log-scale index per (joint, axis) or -1
   int landmarks[6];
+  TreeLevels tree;
 };
 
 struct LossArgs {
@@ -79,6 +91,8 @@ struct AssembleArgs {
   const float* tile_loss;
   const float* qloss;      // weighted silhouette loss of the queued (K-truncated) pixels, one partial per select block
   int nqblk;
+  float* lpart;            // [kAsmLoss] partial sums of the silhouette loss (assemble_kernel)
+  int* counter;            // arrival counter of assemble_kernel's blocks (zero between launches)
   float* g_betas;
   float* g_ls;
   float* g_grot;

@@ -479,6 +479,7 @@ constexpr int kCountShift = 50;
 constexpr float kLogFix = 268435456.0f;   // 2^28
 constexpr int kBandCap = 32;              // per-pixel list of candidates between the two cached depth bounds
 constexpr int kBandFill = 24;             // the select kernel sizes the band to hold at most this many entries
+constexpr int kBandStage = 128;           // band entries staged per wave in the sweep before a batched append
 constexpr float kBandHalf = 8.0f;         // initial half-width of the band, in mean depth gaps of the K nearest
 
 __device__ __forceinline__ unsigned orderable(float f) {
@@ -522,12 +523,13 @@ face_bbox_kernel(ModelDev m, int S, const float* __restrict__ proj, int2* __rest
     if (ok) {
       const float xlo = fminf(ax, fminf(bx, cx)) - kBlurSqrt, xhi = fmaxf(ax, fmaxf(bx, cx)) + kBlurSqrt;
       const float ylo = fminf(ay, fminf(by, cy)) - kBlurSqrt, yhi = fmaxf(ay, fmaxf(by, cy)) + kBlurSqrt;
-      // pixel centre x_p = 1 - (2c+1)/S  =>  c = ((1 - x_p) S - 1) / 2 ; one pixel of slack either side
+      // pixel centre x_p = 1 - (2c+1)/S  =>  c = ((1 - x_p) S - 1) / 2
       const float fs = (float)S;
-      float c0 = floorf(((1.0f - xhi) * fs - 1.0f) * 0.5f) - 1.0f;
-      float c1 = ceilf(((1.0f - xlo) * fs - 1.0f) * 0.5f) + 1.0f;
-      float r0 = floorf(((1.0f - yhi) * fs - 1.0f) * 0.5f) - 1.0f;
-      float r1 = ceilf(((1.0f - ylo) * fs - 1.0f) * 0.5f) + 1.0f;
+      // (floor / ceil leave up to one pixel of slack either side: far more than the rounding of these bounds)
+      float c0 = floorf(((1.0f - xhi) * fs - 1.0f) * 0.5f);
+      float c1 = ceilf(((1.0f - xlo) * fs - 1.0f) * 0.5f);
+      float r0 = floorf(((1.0f - yhi) * fs - 1.0f) * 0.5f);
+      float r1 = ceilf(((1.0f - ylo) * fs - 1.0f) * 0.5f);
       c0 = fminf(fmaxf(c0, 0.f), fs - 1.f); c1 = fminf(fmaxf(c1, -1.f), fs - 1.f);
       r0 = fminf(fmaxf(r0, 0.f), fs - 1.f); r1 = fminf(fmaxf(r1, -1.f), fs - 1.f);
       const bool finite = (xlo == xlo) && (xhi == xhi) && (ylo == ylo) && (yhi == yhi);
@@ -573,9 +575,14 @@ raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, const float2*
   __shared__ int2 boxes[kSweepFaces];
   __shared__ unsigned long long acc[kAccWin * kAccWin];   // near candidates: count << 50 | log sum
   __shared__ int rect[4];
+  // band entries are staged per wave and appended to the per-pixel lists in batches: the append needs the value
+  // returned by a global atomic, and one such round trip per patch would stall the inner loop
+  __shared__ float2 st_e[4][kBandStage];
+  __shared__ int st_p[4][kBandStage];
+  __shared__ int st_n[4];
   const int n = blockIdx.y, t = threadIdx.x;
   const int f0 = blockIdx.x * kSweepFaces;
-  if (t < 4) rect[t] = (t & 1) ? -1 : 0x7fff;          // x0, x1, y0, y1
+  if (t < 4) { rect[t] = (t & 1) ? -1 : 0x7fff; st_n[t] = 0; }   // x0, x1, y0, y1
   for (int i = t; i < kAccWin * kAccWin; i += 256) acc[i] = 0ull;
   __syncthreads();
   if (t < kSweepFaces) {
@@ -597,18 +604,35 @@ raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, const float2*
   const size_t fbase = (size_t)n * S * S;
   unsigned long long* ga = gacc + fbase;
   const float2* zbp = zband + fbase;
-  const int sub = t & 15, lx = sub & 3, ly = sub >> 2, grp = t >> 4;
+  const int sub = t & 15, grp = t >> 4;
   const float inv_s = 1.0f / (float)S;
+  const int wv = t >> 6, lane = t & 63;
+  auto flush_band = [&]() {                              // called with the wave converged
+    const int cnt = min(__builtin_amdgcn_readfirstlane(st_n[wv]), kBandStage);
+    for (int i = lane; i < cnt; i += 64) {
+      const size_t pi = fbase + (size_t)st_p[wv][i];
+      const unsigned slot = atomicAdd(&bcnt[pi], 1u);
+      if (slot < (unsigned)kBandCap) blist[pi * kBandCap + slot] = st_e[wv][i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) st_n[wv] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
   for (int step = 0; step < kSweepFaces / 16; ++step) {
+    if (__builtin_amdgcn_readfirstlane(st_n[wv]) >= kBandStage / 2) flush_band();
     const int k = step * 16 + grp;
     const int2 box = boxes[k];
     const int c0 = box.x & 0xffff, c1 = box.x >> 16, r0 = box.y & 0xffff, r1 = box.y >> 16;
     if (c0 > c1) continue;
-    for (int ry = r0; ry <= r1; ry += 4) {
-      const int row = ry + ly;
-      for (int cx = c0; cx <= c1; cx += 4) {
-        const int col = cx + lx;
-        if (row > r1 || col > c1) continue;
+    // the box's pixels in row-major order, 16 at a time (no lane idles except in the last round)
+    const int bw = c1 - c0 + 1, npx = bw * (r1 - r0 + 1);
+    const float inv_bw = 1.0f / (float)bw;
+    for (int q = sub; q < npx; q += 16) {
+      {
+        int ry = (int)(((float)q + 0.5f) * inv_bw), cx = q - ry * bw;
+        if (cx < 0) { --ry; cx += bw; } else if (cx >= bw) { ++ry; cx -= bw; }
+        const int row = r0 + ry, col = c0 + cx;
         const float2 zb = zbp[row * S + col];
         const float ppx = pix_to_ndc(col, inv_s), ppy = pix_to_ndc(row, inv_s);
         const float pz0 = face_pixel_depth(recs[k], ppx, ppy);
@@ -620,13 +644,20 @@ raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, const float2*
           if (lxw < kAccWin && lyw < kAccWin) atomicAdd(&acc[lyw * kAccWin + lxw], pack_candidate(e.d));
           else atomicAdd(&ga[row * S + col], pack_candidate(e.d));
         } else if (e.pz <= zb.y) {
-          const size_t pi = fbase + (size_t)(row * S + col);
-          const unsigned slot = atomicAdd(&bcnt[pi], 1u);
-          if (slot < (unsigned)kBandCap) blist[pi * kBandCap + slot] = make_float2(e.pz, e.d);
+          const int sl = atomicAdd(&st_n[wv], 1);
+          if (sl < kBandStage) {
+            st_p[wv][sl] = row * S + col;
+            st_e[wv][sl] = make_float2(e.pz, e.d);
+          } else {                                       // staging buffer full: append directly
+            const size_t pi = fbase + (size_t)(row * S + col);
+            const unsigned slot = atomicAdd(&bcnt[pi], 1u);
+            if (slot < (unsigned)kBandCap) blist[pi * kBandCap + slot] = make_float2(e.pz, e.d);
+          }
         }
       }
     }
   }
+  flush_band();
   __syncthreads();
   const int ww = min(kAccWin, rect[1] - wx0 + 1), wh = min(kAccWin, rect[3] - wy0 + 1);
   for (int i = t; i < wh * kAccWin; i += 256) {
@@ -1078,7 +1109,7 @@ raster_bwd_kernel(int F, int S, const float4* __restrict__ frec, const float2* _
                   float* __restrict__ dface /*[M][F][6]*/) {
   const int n = blockIdx.y;
   const int f = blockIdx.x * 16 + (threadIdx.x >> 4);
-  const int sub = threadIdx.x & 15, lx = sub & 3, ly = sub >> 2;
+  const int sub = threadIdx.x & 15;
   float ga[2] = {0.f, 0.f}, gb[2] = {0.f, 0.f}, gc[2] = {0.f, 0.f};
   if (f < F) {
     FaceRec r;
@@ -1088,11 +1119,13 @@ raster_bwd_kernel(int F, int S, const float4* __restrict__ frec, const float2* _
     if (c0 <= c1) {
       const float inv_s = 1.0f / (float)S;
       const float2* gp = gz + (size_t)n * S * S;
-      for (int ry = r0; ry <= r1; ry += 4) {
-        const int row = ry + ly;
-        for (int cx = c0; cx <= c1; cx += 4) {
-          const int col = cx + lx;
-          if (row > r1 || col > c1) continue;
+      const int bw = c1 - c0 + 1, npx = bw * (r1 - r0 + 1);
+      const float inv_bw = 1.0f / (float)bw;
+      for (int q = sub; q < npx; q += 16) {
+        {
+          int ry = (int)(((float)q + 0.5f) * inv_bw), cx = q - ry * bw;
+          if (cx < 0) { --ry; cx += bw; } else if (cx >= bw) { ++ry; cx -= bw; }
+          const int row = r0 + ry, col = c0 + cx;
           const float2 g = gp[row * S + col];
           if (g.x == 0.f) continue;
           PixEval e;
@@ -1220,17 +1253,16 @@ vertex_bwd_kernel(ModelDev m, int M, const float* __restrict__ proj, const float
 }
 
 // K7: dA[n][j] = sum over the skin-weight column of joint j of  w * dvert (x) [v_posed; 1]
-__global__ void __launch_bounds__(128)
-dA_kernel(ModelDev m, const float* __restrict__ dvert, const float* __restrict__ vposed,
-          float* __restrict__ dA /*[M][35][12]*/) {
-  __shared__ float red[16];
-  const int j = blockIdx.x, n = blockIdx.y, Vp = m.Vp;
+__device__ __forceinline__ void
+dA_block(const ModelDev& m, int j, int n, const float* __restrict__ dvert, const float* __restrict__ vposed,
+         float* __restrict__ dA /*[M][35][12]*/, float* red) {
+  const int Vp = m.Vp;
   const float* dv = dvert + (size_t)n * 3 * Vp;
   const float* vp = vposed + (size_t)n * 3 * Vp;
   float acc[12];
 #pragma unroll
   for (int e = 0; e < 12; ++e) acc[e] = 0.f;
-  for (int i = m.wc_off[j] + threadIdx.x; i < m.wc_off[j + 1]; i += 128) {
+  for (int i = m.wc_off[j] + threadIdx.x; i < m.wc_off[j + 1]; i += 256) {
     const int v = m.wc_v[i];
     const float wv = m.wc_val[i];
     const float p[4] = {vp[v], vp[Vp + v], vp[2 * Vp + v], 1.0f};
@@ -1250,176 +1282,307 @@ dA_kernel(ModelDev m, const float* __restrict__ dvert, const float* __restrict__
 
 // K8: pose-blend adjoint  dpf[n][k] = sum_col dvp[n][col] * pd[k][col]   (split over columns)
 // one wave = 16 frames x 8 pose features, lanes stride the 3*Vp columns of its column split.
-constexpr int PB_NT = 16, PB_KT = 8;
-__global__ void __launch_bounds__(64)
-poseblend_bwd_kernel(ModelDev m, int M, int CS, const float* __restrict__ dvp,
-                     float* __restrict__ dpf_part /*[CS][M][308]*/) {
-  const int k0 = blockIdx.x * PB_KT, n0 = blockIdx.y * PB_NT, cs = blockIdx.z;
-  const int lane = threadIdx.x;
+constexpr int PB_NT = 8, PB_KT = 8;
+constexpr int kAsmElem = 4, kAsmLoss = 16;   // assemble_kernel: blocks for element-wise gradients / loss partial sums
+// butterfly reduce-scatter: after folding with bits 32..1 every lane holds the wave-wide sums of two accumulators
+// (indices 2*lane, 2*lane+1) -- 126 shuffles instead of 128 full wave reductions; the summation order is fixed
+template <int HALF>
+__device__ __forceinline__ void fold_accumulators(float* acc, int lane, int bit) {
+#pragma unroll
+  for (int j = 0; j < HALF; ++j) {
+    const bool up = (lane & bit) != 0;
+    const float keep = up ? acc[HALF + j] : acc[j];
+    const float send = up ? acc[j] : acc[HALF + j];
+    acc[j] = keep + __shfl_xor(send, bit, 64);
+  }
+}
+
+// one wave: PB_NT frames x PB_KT pose features over one column split
+__device__ __forceinline__ void
+poseblend_bwd_wave(const ModelDev& m, int M, int CS, int kx, int ny, int cs, int lane, const float* __restrict__ dvp,
+                   float* __restrict__ dpf_part /*[CS][M][308]*/) {
+  const int k0 = kx * PB_KT, n0 = ny * PB_NT;
   const int ncol = 3 * m.Vp;
   const int chunk = ((ncol / 64 + CS - 1) / CS) * 64;
   const int cbeg = cs * chunk, cend = min(ncol, cbeg + chunk);
-  float acc[PB_NT][PB_KT];
+  float acc[PB_NT * PB_KT];
 #pragma unroll
-  for (int i = 0; i < PB_NT; ++i)
+  for (int i = 0; i < PB_NT * PB_KT; ++i) acc[i] = 0.f;
+  float p[PB_KT], d[PB_NT];
+  auto fetch = [&](int c, float* pp, float* dd) {
 #pragma unroll
-    for (int k = 0; k < PB_KT; ++k) acc[i][k] = 0.f;
+    for (int k = 0; k < PB_KT; ++k) pp[k] = (k0 + k < 306 && c < cend) ? m.pd[(size_t)(k0 + k) * ncol + c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < PB_NT; ++i) dd[i] = (n0 + i < M && c < cend) ? dvp[(size_t)(n0 + i) * ncol + c] : 0.f;
+  };
+  fetch(cbeg + lane, p, d);
   for (int c = cbeg + lane; c < cend; c += 64) {
-    float p[PB_KT], d[PB_NT];
-#pragma unroll
-    for (int k = 0; k < PB_KT; ++k) p[k] = (k0 + k < 306) ? m.pd[(size_t)(k0 + k) * ncol + c] : 0.f;
-#pragma unroll
-    for (int i = 0; i < PB_NT; ++i) d[i] = (n0 + i < M) ? dvp[(size_t)(n0 + i) * ncol + c] : 0.f;
+    float pn[PB_KT], dn[PB_NT];
+    fetch(c + 64, pn, dn);                 // next columns in flight while this block of FMAs issues
 #pragma unroll
     for (int i = 0; i < PB_NT; ++i)
 #pragma unroll
-      for (int k = 0; k < PB_KT; ++k) acc[i][k] = fmaf(d[i], p[k], acc[i][k]);
+      for (int k = 0; k < PB_KT; ++k) acc[i * PB_KT + k] = fmaf(d[i], p[k], acc[i * PB_KT + k]);
+#pragma unroll
+    for (int k = 0; k < PB_KT; ++k) p[k] = pn[k];
+#pragma unroll
+    for (int i = 0; i < PB_NT; ++i) d[i] = dn[i];
   }
+  static_assert(PB_NT * PB_KT == 64 || PB_NT * PB_KT == 128, "fold sequence below assumes 64 or 128 accumulators");
+  constexpr int NACC = PB_NT * PB_KT;
+  fold_accumulators<NACC / 2>(acc, lane, 32);
+  fold_accumulators<NACC / 4>(acc, lane, 16);
+  fold_accumulators<NACC / 8>(acc, lane, 8);
+  fold_accumulators<NACC / 16>(acc, lane, 4);
+  fold_accumulators<NACC / 32>(acc, lane, 2);
+  fold_accumulators<NACC / 64>(acc, lane, 1);
+  // every lane now holds the wave-wide sums of accumulators lane * (NACC/64) + r
 #pragma unroll
-  for (int i = 0; i < PB_NT; ++i)
-#pragma unroll
-    for (int k = 0; k < PB_KT; ++k) {
-      const float s = wave_sum(acc[i][k]);
-      if (lane == 0 && n0 + i < M && k0 + k < 306)
-        dpf_part[((size_t)cs * M + n0 + i) * 308 + k0 + k] = s;
-    }
+  for (int r = 0; r < NACC / 64; ++r) {
+    const int e = (NACC / 64) * lane + r, i = e / PB_KT, k = e % PB_KT;
+    if (n0 + i < M && k0 + k < 306) dpf_part[((size_t)cs * M + n0 + i) * 308 + k0 + k] = acc[r];
+  }
 }
 
 // K9: shape-blend adjoint.  shared betas: dbeta_part[block][b] = sum_col sd[b][col] * sum_n dvp[n][col]
 //     per-frame betas (blockIdx.y = frame): no sum over frames.
-__global__ void __launch_bounds__(256)
-dbeta_kernel(ModelDev m, int M, int nb, int shared, const float* __restrict__ dvp,
-             float* __restrict__ dbeta_part /*[nbs][gridDim.z * gridDim.x][nb]*/) {
-  __shared__ float red[16];
+__device__ __forceinline__ void
+dbeta_block(const ModelDev& m, int M, int nb, int shared, int bx, int by, int bz, int gx, int gzn,
+            const float* __restrict__ dvp, float* __restrict__ dbeta_part /*[nbs][gzn * gx][nb]*/, float* red) {
   const int ncol = 3 * m.Vp;
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int c = bx * 256 + threadIdx.x;
   float g = 0.f;
   if (c < ncol) {
-    if (shared) {       // frames are split over blockIdx.z
-      const int per = (M + gridDim.z - 1) / gridDim.z;
-      const int n0 = blockIdx.z * per, n1 = min(M, n0 + per);
+    if (shared) {       // frames are split over bz
+      const int per = (M + gzn - 1) / gzn;
+      const int n0 = bz * per, n1 = min(M, n0 + per);
       for (int n = n0; n < n1; ++n) g += dvp[(size_t)n * ncol + c];
     } else {
-      g = dvp[(size_t)blockIdx.y * ncol + c];
+      g = dvp[(size_t)by * ncol + c];
     }
   }
-  const size_t part = (size_t)blockIdx.y * gridDim.z * gridDim.x + (size_t)blockIdx.z * gridDim.x + blockIdx.x;
+  const size_t part = (size_t)by * gzn * gx + (size_t)bz * gx + bx;
   for (int b = 0; b < nb; ++b) {
     const float s = block_sum((c < ncol) ? g * m.sd[(size_t)b * ncol + c] : 0.f, red);
     if (threadIdx.x == 0) dbeta_part[part * nb + b] = s;
   }
 }
 
+// everything between the vertex adjoint and the chain adjoint in ONE launch (the three parts are independent and
+// each is latency-bound on its own): blocks [0, nPB) pose-blend adjoint (4 waves = 4 tiles), then 35 x M blocks
+// dA_j, then the shape-blend adjoint partials.
+__global__ void __launch_bounds__(256)
+lbs_bwd_mid_kernel(ModelDev m, int M, int CS, int nb, int betas_shared, int nPB, int nDB_x, int nDB_y, int nDB_z,
+                   const float* __restrict__ dvert, const float* __restrict__ vposed, const float* __restrict__ dvp,
+                   float* __restrict__ dA, float* __restrict__ dpf_part, float* __restrict__ dbeta_part) {
+  __shared__ float red[16];
+  int blk = blockIdx.x;
+  if (blk < nPB) {
+    const int nkx = (306 + PB_KT - 1) / PB_KT, nny = (M + PB_NT - 1) / PB_NT;
+    const int vb = blk * 4 + (threadIdx.x >> 6);
+    if (vb < nkx * nny * CS) poseblend_bwd_wave(m, M, CS, vb % nkx, (vb / nkx) % nny, vb / (nkx * nny), threadIdx.x & 63, dvp, dpf_part);
+    return;
+  }
+  blk -= nPB;
+  if (blk < 35 * M) { dA_block(m, blk % 35, blk / 35, dvert, vposed, dA, red); return; }
+  blk -= 35 * M;
+  if (blk < nDB_x * nDB_y * nDB_z)
+    dbeta_block(m, M, nb, betas_shared, blk % nDB_x, (blk / nDB_x) % nDB_y, blk / (nDB_x * nDB_y), nDB_x, nDB_z, dvp, dbeta_part, red);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K10: per-frame chain adjoint: dA, dpf -> d theta, d logscale, d rest joints
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 chain_bwd_kernel(ModelDev m, int M, const float* __restrict__ theta, const float* __restrict__ Rm,
                  const float* __restrict__ Gm, const float* __restrict__ scm,
                  const float* __restrict__ Jrest, int j_stride, const float* __restrict__ dA,
                  const float* __restrict__ dpf_part, int CS, const float* __restrict__ dth_direct,
                  float* __restrict__ dtheta /*[M][105]*/, float* __restrict__ dls /*[M][6]*/,
                  float* __restrict__ dJrest /*[M][105]*/, float* __restrict__ dbetaJ /*[M][NBall] or null*/) {
+  // One block per frame: 256 threads for the loads / reductions at either end (latency), the first wave walks the
+  // tree.  The tree is walked by depth (TreeLevels), 12 lanes per joint of the level.  Every joint
+  // writes what it owes its parent into its own slots (cG, cJ, cS) and parents gather from their children in
+  // descending joint order, so no two lanes ever add into the same word (deterministic).
   __shared__ float R[35][9], G[35][12], sc[35][3], J[35][3];
-  __shared__ float dG[35][12], dR[35][9], dsc[35][3], dJ[35][3];
-  __shared__ float dRp[9], dj[3];
-  __shared__ int par[35];
+  __shared__ float dG[35][12], dR[35][9], dJ[35][3];
+  __shared__ float cG[35][12], cJ[35][3], cS[35][3], sOwn[35][3];
+  __shared__ float dRp[35][9], djv[35][3];
+  __shared__ int sidx[105];
+  __shared__ float psum[4][320];
+  __shared__ float isc[35][3];          // 1 / s_j[a]
+  __shared__ float sJS[105 * 48];       // d(rest joints)/d(beta), staged while the tree is walked
+  __shared__ unsigned char t_lvl_off[36], t_lvl_joint[36], t_child_off[36], t_child_idx[36], t_par[36];
   const int n = blockIdx.x, l = threadIdx.x;
-  for (int i = l; i < 315; i += 64) R[i / 9][i % 9] = Rm[(size_t)n * 315 + i];
-  for (int i = l; i < 420; i += 64) G[i / 12][i % 12] = Gm[(size_t)n * 420 + i];
-  for (int i = l; i < 105; i += 64) {
-    sc[i / 3][i % 3] = scm[(size_t)n * 105 + i];
-    J[i / 3][i % 3] = Jrest[(size_t)n * j_stride + i];
-    dsc[i / 3][i % 3] = 0.f;
+  const TreeLevels& tl = m.tree;
+  if (l < 36) {
+    t_lvl_off[l] = tl.lvl_off[l]; t_child_off[l] = tl.child_off[l];
+    if (l < 35) { t_lvl_joint[l] = tl.lvl_joint[l]; t_child_idx[l] = tl.child_idx[l]; t_par[l] = (unsigned char)max(m.parents[l], 0); }
   }
-  if (l < 35) par[l] = m.parents[l];
-  // pose-feature adjoint -> dR of joints 1..34 ; root starts at 0
-  for (int i = l; i < 315; i += 64) {
-    float s = 0.f;
-    if (i >= 9 && dpf_part) for (int c = 0; c < CS; ++c) s += dpf_part[((size_t)c * M + n) * 308 + (i - 9)];
-    dR[i / 9][i % 9] = s;
+  const int nlev = tl.nlev;
+  const bool js_lds = dbetaJ && m.NBall <= 48;
+  if (js_lds) for (int i = l; i < 105 * m.NBall; i += 256) sJS[i] = m.JS[i];
+  for (int i = l; i < 315; i += 256) R[i / 9][i % 9] = Rm[(size_t)n * 315 + i];
+  for (int i = l; i < 420; i += 256) G[i / 12][i % 12] = Gm[(size_t)n * 420 + i];
+  for (int i = l; i < 105; i += 256) {
+    { const float sv = scm[(size_t)n * 105 + i]; sc[i / 3][i % 3] = sv; isc[i / 3][i % 3] = 1.0f / sv; }
+    J[i / 3][i % 3] = Jrest[(size_t)n * j_stride + i];
+    sOwn[i / 3][i % 3] = 0.f; cS[i / 3][i % 3] = 0.f; cJ[i / 3][i % 3] = 0.f;
+    sidx[i] = m.scale_idx[i];
+  }
+  // pose-feature adjoint -> dR of joints 1..34: sum of the column-split partials in a fixed order (four quarters of
+  // the splits in parallel, then the quarters); root starts at 0
+  if (dpf_part) {
+    const int per = (CS + 3) / 4, q = l >> 6, c0 = q * per, c1 = min(CS, c0 + per);
+    const size_t stride = (size_t)M * 308;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const int el = (l & 63) + 64 * r;
+      if (el < 306) {
+        const float* src = dpf_part + (size_t)n * 308 + el;
+        float sacc = 0.f;
+        if (c1 - c0 == 4) {                      // the usual case: four independent loads in flight
+          const float v0 = src[c0 * stride], v1 = src[(c0 + 1) * stride], v2 = src[(c0 + 2) * stride], v3 = src[(c0 + 3) * stride];
+          sacc = ((v0 + v1) + v2) + v3;
+        } else {
+          for (int c = c0; c < c1; ++c) sacc += src[c * stride];
+        }
+        psum[q][el] = sacc;
+      }
+    }
   }
   __syncthreads();
+  for (int i = l; i < 315; i += 256)
+    dR[i / 9][i % 9] = (i >= 9 && dpf_part) ? ((psum[0][i - 9] + psum[1][i - 9]) + psum[2][i - 9]) + psum[3][i - 9] : 0.f;
   // A_j = [G.R | G.t - G.R J_j]
-  for (int i = l; i < 420; i += 64) {
+  for (int i = l; i < 420; i += 256) {
     const int j = i / 12, e = i % 12, a = e >> 2, b = e & 3;
     const float* da = dA + ((size_t)n * 35 + j) * 12;
     dG[j][e] = (b < 3) ? da[e] - da[a * 4 + 3] * J[j][b] : da[e];
   }
-  for (int i = l; i < 105; i += 64) {
+  for (int i = l; i < 105; i += 256) {
     const int j = i / 3, c = i % 3;
     const float* da = dA + ((size_t)n * 35 + j) * 12;
     dJ[j][c] = -(G[j][0 * 4 + c] * da[3] + G[j][1 * 4 + c] * da[7] + G[j][2 * 4 + c] * da[11]);
   }
   __syncthreads();
-  for (int i = 34; i >= 1; --i) {
-    const int p = par[i];
-    // phase 1: dR' = G_p.R^T dG_i.R ; dj = G_p.R^T dG_i.t
-    if (l < 9) {
-      const int a = l / 3, b = l % 3;
-      dRp[l] = G[p][0 * 4 + a] * dG[i][0 * 4 + b] + G[p][1 * 4 + a] * dG[i][1 * 4 + b] + G[p][2 * 4 + a] * dG[i][2 * 4 + b];
-    } else if (l < 12) {
-      const int a = l - 9;
-      dj[a] = G[p][0 * 4 + a] * dG[i][3] + G[p][1 * 4 + a] * dG[i][7] + G[p][2 * 4 + a] * dG[i][11];
-    }
-    __syncthreads();
-    // phase 2: accumulate into the parent and the local rotation / scales / joints
-    if (l < 9) {
-      const int a = l / 3, c = l % 3;
-      // dG_p.R[a][c] += sum_b dG_i.R[a][b] R'[c][b] + dG_i.t[a] (J_i - J_p)[c]
-      float acc = dG[i][a * 4 + 3] * (J[i][c] - J[p][c]);
+  const int slot = l / 12, e = l % 12;
+  if (l < 64)   // the walk needs 60 lanes: one wave, no block barriers (LDS operations of a wave complete in order)
+  for (int L = nlev - 1; L >= 1; --L) {
+    const int j0 = t_lvl_off[L], nj = t_lvl_off[L + 1] - j0;
+    for (int base = 0; base < nj; base += 5) {           // 5 joints x 12 lanes per pass
+      const bool live = (slot < 5) && (base + slot < nj);
+      const int i = live ? t_lvl_joint[j0 + base + slot] : 0;
+      const int p = live ? t_par[i] : 0;
+      // gather what the children owe this joint's dG (children were finished one level deeper)
+      if (live) {
+        float acc = dG[i][e];
+        for (int q = t_child_off[i]; q < t_child_off[i + 1]; ++q) acc += cG[t_child_idx[q]][e];
+        dG[i][e] = acc;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      // dR' = G_p.R^T dG_i.R ; dj = G_p.R^T dG_i.t
+      if (live) {
+        if (e < 9) {
+          const int a = e / 3, b = e % 3;
+          dRp[i][e] = G[p][0 * 4 + a] * dG[i][0 * 4 + b] + G[p][1 * 4 + a] * dG[i][1 * 4 + b] + G[p][2 * 4 + a] * dG[i][2 * 4 + b];
+        } else {
+          const int a = e - 9;
+          djv[i][a] = G[p][0 * 4 + a] * dG[i][3] + G[p][1 * 4 + a] * dG[i][7] + G[p][2 * 4 + a] * dG[i][11];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (live) {
+        if (e < 9) {
+          const int a = e / 3, c = e % 3;
+          // owed to dG_p.R[a][c]: sum_b dG_i.R[a][b] R'[c][b] + dG_i.t[a] (J_i - J_p)[c]
+          float acc = dG[i][a * 4 + 3] * (J[i][c] - J[p][c]);
 #pragma unroll
-      for (int b = 0; b < 3; ++b) acc = fmaf(dG[i][a * 4 + b], R[i][c * 3 + b] * sc[i][b] / sc[p][c], acc);
-      dG[p][a * 4 + c] += acc;
-      // dR_i[a][c] += dR'[a][c] s_i[c] / s_p[a]
-      dR[i][a * 3 + c] += dRp[a * 3 + c] * sc[i][c] / sc[p][a];
-    } else if (l < 12) {
-      const int a = l - 9;
-      dG[p][a * 4 + 3] += dG[i][a * 4 + 3];
-      dJ[i][a] += dj[a];
-      dJ[p][a] -= dj[a];
-    } else if (l < 15) {
-      const int b = l - 12;       // ds_i[b] += sum_a dR'[a][b] R_i[a][b] / s_p[a]
-      float acc = 0.f;
+          for (int b = 0; b < 3; ++b) acc = fmaf(dG[i][a * 4 + b], R[i][c * 3 + b] * sc[i][b] * isc[p][c], acc);
+          cG[i][a * 4 + c] = acc;
+          // dR_i[a][c] += dR'[a][c] s_i[c] / s_p[a]
+          dR[i][a * 3 + c] += dRp[i][a * 3 + c] * sc[i][c] * isc[p][a];
+        } else {
+          const int a = e - 9;
+          cG[i][a * 4 + 3] = dG[i][a * 4 + 3];
+          cJ[i][a] = djv[i][a];                          // dJ_i += dj, dJ_p -= dj (applied after the walk)
+          {                                              // ds_i[b] += sum_a dR'[a][b] R_i[a][b] / s_p[a]   (b = a here)
+            const int b = a;
+            float acc = 0.f;
 #pragma unroll
-      for (int a = 0; a < 3; ++a) acc = fmaf(dRp[a * 3 + b], R[i][a * 3 + b] / sc[p][a], acc);
-      dsc[i][b] += acc;
-    }
-    __syncthreads();
-    if (l < 3) {
-      const int a = l;            // ds_p[a] -= sum_b dR'[a][b] R'[a][b] / s_p[a]
-      float acc = 0.f;
+            for (int r = 0; r < 3; ++r) acc = fmaf(dRp[i][r * 3 + b], R[i][r * 3 + b] * isc[p][r], acc);
+            sOwn[i][b] = acc;
+          }
+          {                                              // ds_p[a] -= sum_b dR'[a][b] R'[a][b] / s_p[a]
+            float acc = 0.f;
 #pragma unroll
-      for (int b = 0; b < 3; ++b) acc = fmaf(dRp[a * 3 + b], R[i][a * 3 + b] * sc[i][b] / sc[p][a], acc);
-      dsc[p][a] -= acc / sc[p][a];
+            for (int b = 0; b < 3; ++b) acc = fmaf(dRp[i][a * 3 + b], R[i][a * 3 + b] * sc[i][b] * isc[p][a], acc);
+            cS[i][a] = acc * isc[p][a];
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
   }
+  __syncthreads();
+  // root: gather its children, then its own rotation / joint adjoint
+  if (l < 12) {
+    float acc = dG[0][l];
+    for (int q = t_child_off[0]; q < t_child_off[1]; ++q) acc += cG[t_child_idx[q]][l];
+    dG[0][l] = acc;
+  }
+  __syncthreads();
   if (l < 9) dR[0][l] += dG[0][(l / 3) * 4 + (l % 3)];
-  if (l < 3) dJ[0][l] += dG[0][l * 4 + 3];
+  // joint and scale adjoints: children first (descending), then the joint's own term -- the order of a reverse loop
+  for (int i = l; i < 105; i += 256) {
+    const int j = i / 3, a = i % 3;
+    float aj = dJ[j][a], as = 0.f;
+    for (int q = t_child_off[j]; q < t_child_off[j + 1]; ++q) { aj -= cJ[t_child_idx[q]][a]; as -= cS[t_child_idx[q]][a]; }
+    if (j > 0) { aj += cJ[j][a]; as += sOwn[j][a]; }
+    else aj += dG[0][a * 4 + 3];
+    dJ[j][a] = aj;
+    sOwn[j][a] = as;                                      // now the full d loss / d s_j[a]
+  }
   __syncthreads();
   if (l < 35) {
     const float th[3] = {theta[(n * 35 + l) * 3], theta[(n * 35 + l) * 3 + 1], theta[(n * 35 + l) * 3 + 2]};
     float g[9], d[3];
 #pragma unroll
-    for (int e = 0; e < 9; ++e) g[e] = dR[l][e];
+    for (int q = 0; q < 9; ++q) g[q] = dR[l][q];
     rodrigues_bwd(th, g, d);
 #pragma unroll
     for (int a = 0; a < 3; ++a)
       dtheta[(size_t)n * 105 + l * 3 + a] = d[a] + (dth_direct ? dth_direct[(size_t)n * 105 + l * 3 + a] : 0.f);
   }
-  if (l < 6 && dls) {
-    float acc = 0.f;
-    for (int i = 0; i < 105; ++i)
-      if (m.scale_idx[i] == l) acc += dsc[i / 3][i % 3] * sc[i / 3][i % 3];
-    dls[(size_t)n * 6 + l] = acc;
+  if (dls) {                                     // d log-scale: 6 masked sums over the 105 (joint, axis) scales
+    const int w = l >> 6, lane = l & 63;
+    for (int sidx_l = w; sidx_l < 6; sidx_l += 4) {
+      float v = 0.f;
+      if (sidx[lane] == sidx_l) v = sOwn[lane / 3][lane % 3] * sc[lane / 3][lane % 3];
+      if (lane + 64 < 105 && sidx[lane + 64] == sidx_l) v += sOwn[(lane + 64) / 3][(lane + 64) % 3] * sc[(lane + 64) / 3][(lane + 64) % 3];
+      v = wave_sum(v);
+      if (lane == 0) dls[(size_t)n * 6 + sidx_l] = v;
+    }
   }
-  for (int i = l; i < 105; i += 64) dJrest[(size_t)n * 105 + i] = dJ[i / 3][i % 3];
-  // rest joints are affine in beta (J = Jt + JS beta): d beta through the joints
-  if (dbetaJ && l < m.NBall) {
-    float acc = 0.f;
-    for (int i = 0; i < 105; ++i) acc = fmaf(dJ[i / 3][i % 3], m.JS[i * m.NBall + l], acc);
-    dbetaJ[(size_t)n * m.NBall + l] = acc;
+  for (int i = l; i < 105; i += 256) dJrest[(size_t)n * 105 + i] = dJ[i / 3][i % 3];
+  // rest joints are affine
+  if (dbetaJ) {
+    const int w = l >> 6, b = l & 63;
+    if (b < m.NBall) {
+      float acc = 0.f;
+      if (js_lds) {
+#pragma unroll 9
+        for (int r = 0; r < 27; ++r) { const int i = w * 27 + r; if (i < 105) acc = fmaf(dJ[i / 3][i % 3], sJS[i * m.NBall + b], acc); }
+      } else {
+        for (int i = w * 27; i < min(105, w * 27 + 27); ++i) acc = fmaf(dJ[i / 3][i % 3], m.JS[i * m.NBall + b], acc);
+      }
+      psum[w][b] = acc;
+    }
+    __syncthreads();
+    if (l < m.NBall) dbetaJ[(size_t)n * m.NBall + l] = ((psum[0][l] + psum[1][l]) + psum[2][l]) + psum[3][l];
   }
 }
 
@@ -1428,18 +1591,26 @@ chain_bwd_kernel(ModelDev m, int M, const float* __restrict__ theta, const float
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 assemble_kernel(AssembleArgs a) {
+  // Blocks take roles (kAsmElem / kAsmLoss are compile-time):
+  //   [0, nbs)            d loss / d betas of shape set s: column-block partials + joint path + prior
+  //   nbs                 limb scales
+  //   next kAsmElem       rotations / translation: masks, vertex-block partials
+  //   next kAsmLoss       partial sums of the silhouette loss
+  // and the block that finishes last adds up the eight loss terms (fixed order: deterministic).
   __shared__ float red[16];
   __shared__ float bsum[12][64];
+  __shared__ float part[32][8];
+  __shared__ int is_last;
   const int t = threadIdx.x;
   const int M = a.M;
-  // betas: sum of column-block partials + sum_n JS^T dJrest[n] + prior
-  if (a.g_betas) {
-    const int nbs = a.betas_shared ? 1 : M;
-    for (int s = 0; s < nbs; ++s) {
-      // 12 slices x nb(<=20, padded to 64 slots) partial sums, then a short serial combine
+  const int nbs = a.betas_shared ? 1 : M;
+  int role = blockIdx.x;
+  if (role < nbs) {
+    if (a.g_betas) {
+      const int s = role;
       const int b = t % 20, slice = t / 20;
-      float acc = 0.f;
       if (slice < 12 && b < a.nb) {
+        float acc = 0.f;
         const int nlo = a.betas_shared ? 0 : s, nhi = a.betas_shared ? M : s + 1;
         for (int n = nlo + slice; n < nhi; n += 12) acc += a.dbetaJ[(size_t)n * a.NBall + b];
         const int nparts = a.nblk_beta * a.ngrp_beta;
@@ -1453,55 +1624,72 @@ assemble_kernel(AssembleArgs a) {
         if (a.gb_prior && s == 0) tot += a.gb_prior[t];
         a.g_betas[s * a.nb + t] = tot;
       }
-      __syncthreads();
     }
-  }
-  if (a.g_ls) {
-    if (a.ls_shared) {
-      if (t < 6) {
+  } else if ((role -= nbs) == 0) {
+    if (a.g_ls) {
+      if (a.ls_shared) {
+        // 6 scales x 32 frame slices
+        const int e = t & 7, sl = t >> 3;
         float acc = 0.f;
-        for (int n = 0; n < M; ++n) acc += a.dls[(size_t)n * 6 + t];
-        if (a.gls_prior) acc += a.gls_prior[t];
-        a.g_ls[t] = acc;
+        if (e < 6) for (int n = sl; n < M; n += 32) acc += a.dls[(size_t)n * 6 + e];
+        part[sl][e] = acc;                 // then the 32 slices of each scale in a fixed order
+        __syncthreads();
+        if (t < 6) {
+          float tot = 0.f;
+          for (int i = 0; i < 32; ++i) tot += part[i][t];
+          if (a.gls_prior) tot += a.gls_prior[t];
+          a.g_ls[t] = tot;
+        }
+      } else {
+        for (int i = t; i < M * 6; i += 256) a.g_ls[i] = a.dls[i];
       }
-    } else {
-      for (int i = t; i < M * 6; i += 256) a.g_ls[i] = a.dls[i];
     }
-  }
-  for (int i = t; i < M * 3; i += 256) {
-    const int n = i / 3, e = i % 3;
-    if (a.g_grot) a.g_grot[i] = a.dtheta[(size_t)n * 105 + e] * a.gmask[e];
-    if (a.g_trans) {
-      float acc = a.dtr_direct ? a.dtr_direct[i] : 0.f;
-      for (int vt = 0; vt < a.nvt; ++vt) acc += a.dtr_part[((size_t)vt * M + n) * 3 + e];
-      a.g_trans[i] = acc;
+  } else if ((role -= 1) < kAsmElem) {
+    const int gt = role * 256 + t, gs = kAsmElem * 256;
+    for (int i = gt; i < M * 3; i += gs) {
+      const int n = i / 3, e = i % 3;
+      if (a.g_grot) a.g_grot[i] = a.dtheta[(size_t)n * 105 + e] * a.gmask[e];
+      if (a.g_trans) {
+        float acc = a.dtr_direct ? a.dtr_direct[i] : 0.f;
+        for (int vt = 0; vt < a.nvt; ++vt) acc += a.dtr_part[((size_t)vt * M + n) * 3 + e];
+        a.g_trans[i] = acc;
+      }
     }
-  }
-  if (a.g_jrot)
-    for (int i = t; i < M * 102; i += 256) {
-      const int n = i / 102, e = i % 102;
-      a.g_jrot[i] = a.dtheta[(size_t)n * 105 + 3 + e] * a.rmask[e];
-    }
-  // losses: [joint, pose, splay, betas, sil, temp_joint, temp_global, temp_trans]
-  if (a.losses) {
+    if (a.g_jrot)
+      for (int i = gt; i < M * 102; i += gs) {
+        const int n = i / 102, e = i % 102;
+        a.g_jrot[i] = a.dtheta[(size_t)n * 105 + 3 + e] * a.rmask[e];
+      }
+  } else if (a.losses) {
+    role -= kAsmElem;                    // [0, kAsmLoss)
     float lsil = 0.f;
     if (a.tile_loss) {
-      for (int k = t; k < M * a.T; k += 256) {
+      for (int k = role * 256 + t; k < M * a.T; k += kAsmLoss * 256) {
         const int n = k / a.T;
         const int Bn = frame_window_size(n, M, a.window);
         lsil += a.tile_loss[k] * (a.w_sil / ((float)Bn * (float)a.S * (float)a.S));
       }
     }
-    if (a.qloss) for (int k = t; k < a.nqblk; k += 256) lsil += a.qloss[k];
+    if (a.qloss) for (int k = role * 256 + t; k < a.nqblk; k += kAsmLoss * 256) lsil += a.qloss[k];
     lsil = block_sum(lsil, red);
-    if (t < 8) {
-      float acc = 0.f;
-      if (t == 3) acc = a.loss_betas ? *a.loss_betas : 0.f;
-      else if (t == 4) acc = lsil;
-      else if (a.loss_part) for (int n = 0; n < M; ++n) acc += a.loss_part[n * 8 + t];
-      a.losses[t] = acc;
-    }
+    if (t == 0) a.lpart[role] = lsil;
   }
+  if (!a.losses) return;
+  // ---- the last block to arrive finishes the loss terms: [joint, pose, splay, betas, sil, temp_joint, temp_global, temp_trans]
+  __threadfence();
+  __syncthreads();
+  if (t == 0) is_last = (atomicAdd(a.counter, 1) == (int)gridDim.x - 1);
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  if (t < 8) {
+    float acc = 0.f;
+    if (t == 3) acc = a.loss_betas ? *a.loss_betas : 0.f;
+    else if (t == 4) { const volatile float* lp = a.lpart; for (int i = 0; i < kAsmLoss; ++i) acc += lp[i]; }
+    else if (a.loss_part) for (int n = 0; n < M; ++n) acc += a.loss_part[n * 8 + t];
+    a.losses[t] = acc;
+  }
+  if (t == 0) *a.counter = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
