@@ -463,7 +463,7 @@ shape_prior_kernel(const float* __restrict__ betas, const float* __restrict__ lo
 //              screen-space neighbours in any pose.
 //   sweep      one block per 128 consecutive faces: candidates are accumulated in a 64x64-pixel LDS window
 //              anchored at the block's union box as ONE packed 64-bit integer per pixel
-//              (count << 50 | sum of -log2(1 - p) in 2^-28 fixed point) and flushed with one global atomic
+//              (count << 50 | sum of -log2(1 - p) in 2^-24 fixed point) and flushed with one global atomic
 //              per touched pixel (10-27x fewer than one per candidate).  Integer adds commute: the result does
 //              not depend on arrival order (deterministic).
 //   resolve    thread per pixel: alpha = 2^-sum.  Pixels with more than K candidates get one wave each: it
@@ -476,7 +476,7 @@ constexpr int kRectFaces = 8;             // faces per entry of the union-box in
 constexpr int kSweepFaces = 128;          // faces per sweep block
 constexpr int kAccWin = 48;               // LDS accumulator window edge (pixels); outside: global atomics
 constexpr int kCountShift = 50;
-constexpr float kLogFix = 268435456.0f;   // 2^28
+constexpr float kLogFix = 16777216.0f;    // 2^24
 constexpr int kBandCap = 32;              // per-pixel list of candidates between the two cached depth bounds
 constexpr int kBandFill = 24;             // the select kernel sizes the band to hold at most this many entries
 constexpr int kBandStage = 128;           // band entries staged per wave in the sweep before a batched append
@@ -498,20 +498,35 @@ __device__ __forceinline__ bool box_contains(int2 b, int x, int y) {
   return (b.x & 0xffff) <= x && x <= (b.x >> 16) && (b.y & 0xffff) <= y && y <= (b.y >> 16);
 }
 __device__ __forceinline__ unsigned long long pack_candidate(float d) {
-  // count in the top bits, -log2(1 - p) in [0, 256] as 2^-28 fixed point (integer and fractional part separately:
-  // there is no native float -> u64 conversion)
-  const float f = -log2_one_minus_prob(d);
-  const float ip = floorf(f);
-  return (1ull << kCountShift) | ((unsigned long long)(unsigned)ip << 28) | (unsigned long long)(unsigned)((f - ip) * kLogFix);
+  // count in the top bits, -log2(1 - p) = -log2 sigmoid(d / sigma) in [0, 256) as 2^-24 fixed point.
+  // v_exp_f32 / v_log_f32 directly (1 ulp; the argument ranges need no denormal handling: 2^-|x| only matters while
+  // it is > 2^-24 next to 1).  One rounded term is off by <= 6e-8 relative in alpha, like a rounded multiplication.
+  const float x2 = d * (1.4426950408889634f / kSigma);
+  const float t = __builtin_amdgcn_exp2f(-fabsf(x2));
+  const float f = fminf(__builtin_amdgcn_logf(1.0f + t) - fminf(x2, 0.0f), 255.99998f);
+  return (1ull << kCountShift) | (unsigned long long)(unsigned)(f * kLogFix);
+}
+
+// p = sigmoid(-d / sigma) with the hardware exp2 / rcp (backward sweep)
+__device__ __forceinline__ float prob_fast(float d) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(d * (1.4426950408889634f / kSigma)));
 }
 
 // 5a: per-face validity, conservative pixel box, packed record; union box per 32 faces
 __global__ void __launch_bounds__(256)
 face_bbox_kernel(ModelDev m, int S, const float* __restrict__ proj, int2* __restrict__ fbox,
-                 float4* __restrict__ frec /*[M][F][3]*/, int4* __restrict__ brect /*[M][ceil(F/32)]*/) {
+                 float4* __restrict__ frec /*[M][F][3]*/, int4* __restrict__ brect /*[M][ceil(F/32)]*/,
+                 float* __restrict__ zc /*[M]*/) {
   const int f = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
   const int Vp = m.Vp;
   const float* px = proj + (size_t)n * 3 * Vp;
+  // reference depth of the frame (mean over 64 spread vertices).  The rasteriser orders candidates by pz - zc, which
+  // is the same order (the subtraction is exact for depths within a factor two) but keeps the cached per-pixel
+  // bounds valid when the whole animal moves along the view axis.
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    const float zsum = wave_sum(px[2 * Vp + (int)(((long long)threadIdx.x * m.V) >> 6)]);
+    if (threadIdx.x == 0) zc[n] = zsum * (1.0f / 64.0f);
+  }
   int2 box = make_int2(1, 1);     // c0=1 > c1=0 : empty
   if (f < m.F) {
     const int i0 = m.faces[f * 3], i1 = m.faces[f * 3 + 1], i2 = m.faces[f * 3 + 2];
@@ -568,7 +583,7 @@ __device__ __forceinline__ bool load_face_rec(const float4* __restrict__ fr, Fac
 // are dropped.  raster_resolve_kernel proves from the counts that the K nearest are {<= lo} + the nearest few of the
 // band, or sends the pixel to the exact selection.
 __global__ void __launch_bounds__(256)
-raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, const float2* __restrict__ zband,
+raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, const float* __restrict__ zc, const float2* __restrict__ zband,
                     unsigned long long* __restrict__ gacc /*[M][S*S]*/, unsigned* __restrict__ bcnt /*[M][S*S]*/,
                     float2* __restrict__ blist /*[M][S*S][kBandCap]*/) {
   __shared__ __attribute__((aligned(16))) FaceRec recs[kSweepFaces];
@@ -607,6 +622,7 @@ raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, const float2*
   const int sub = t & 15, grp = t >> 4;
   const float inv_s = 1.0f / (float)S;
   const int wv = t >> 6, lane = t & 63;
+  const float zcn = zc[n];
   auto flush_band = [&]() {                              // called with the wave converged
     const int cnt = min(__builtin_amdgcn_readfirstlane(st_n[wv]), kBandStage);
     for (int i = lane; i < cnt; i += 64) {
@@ -635,23 +651,23 @@ raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, const float2*
         const int row = r0 + ry, col = c0 + cx;
         const float2 zb = zbp[row * S + col];
         const float ppx = pix_to_ndc(col, inv_s), ppy = pix_to_ndc(row, inv_s);
-        const float pz0 = face_pixel_depth(recs[k], ppx, ppy);
-        if (!(pz0 <= zb.y)) continue;                  // beyond the pixel's far bound: dropped whatever its distance
+        const float rz = face_pixel_depth(recs[k], ppx, ppy) - zcn;   // depth relative to the frame reference
+        if (!(rz <= zb.y)) continue;                   // beyond the pixel's far bound: dropped whatever its distance
         PixEval e;
         if (!face_pixel_eval(recs[k], ppx, ppy, e)) continue;
-        if (e.pz <= zb.x) {
+        if (rz <= zb.x) {
           const int lxw = col - wx0, lyw = row - wy0;
           if (lxw < kAccWin && lyw < kAccWin) atomicAdd(&acc[lyw * kAccWin + lxw], pack_candidate(e.d));
           else atomicAdd(&ga[row * S + col], pack_candidate(e.d));
-        } else if (e.pz <= zb.y) {
+        } else {
           const int sl = atomicAdd(&st_n[wv], 1);
           if (sl < kBandStage) {
             st_p[wv][sl] = row * S + col;
-            st_e[wv][sl] = make_float2(e.pz, e.d);
+            st_e[wv][sl] = make_float2(rz, e.d);
           } else {                                       // staging buffer full: append directly
             const size_t pi = fbase + (size_t)(row * S + col);
             const unsigned slot = atomicAdd(&bcnt[pi], 1u);
-            if (slot < (unsigned)kBandCap) blist[pi * kBandCap + slot] = make_float2(e.pz, e.d);
+            if (slot < (unsigned)kBandCap) blist[pi * kBandCap + slot] = make_float2(rz, e.d);
           }
         }
       }
@@ -708,7 +724,11 @@ raster_resolve_kernel(int S, int M, int window, float w_sil, const unsigned long
     else if (need == 0) zthr = zb.x;                              // exactly K at or below lo
     else if (need > b) action = (zb.y < kInf) ? 1 : (b == 0 ? 0 : 2);   // hi = +inf: fewer than K candidates in all
     else action = 2;
-    if (stats && zb.x < kInf) { atomicAdd(&stats[1], 1); if (action != 1) { atomicAdd(&stats[2], 1); atomicAdd(&stats[3], b); } }
+    if (stats && zb.x < kInf) {
+      atomicAdd(&stats[1], 1);
+      if (action != 1) { atomicAdd(&stats[2], 1); atomicAdd(&stats[3], b); }
+      else atomicAdd(&stats[need < 0 ? 4 : (b > kBandCap ? 5 : 6)], 1);
+    }
     if (action == 0) {
       const float alpha = (c > 0) ? (float)exp2(-(double)(vb & kSumMask) * (1.0 / (double)kLogFix)) : 1.0f;
       const float sil = 1.0f - alpha;
@@ -824,7 +844,7 @@ constexpr int kCoverCap = 2048;           // faces whose box covers the pixel, k
 constexpr int kSelWaves = 2;              // waves per select block: 13 KB of LDS per wave -> 6 blocks (12 waves) per CU
 
 __global__ void __launch_bounds__(64 * kSelWaves)
-raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4* __restrict__ frec,
+raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4* __restrict__ frec, const float* __restrict__ zc,
                      const int4* __restrict__ brect, const int2* __restrict__ fbox, const int* __restrict__ qcount,
                      const int* __restrict__ queue, const float* __restrict__ tsil,
                      float* __restrict__ sil_out, float2* __restrict__ gz, float2* __restrict__ zband,
@@ -850,6 +870,7 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
     const int n = gp / npix, pix = gp % npix;
     const int pcol = pix % S, prow = pix / S;
     const float ppx = pix_to_ndc(pcol, inv_s), ppy = pix_to_ndc(prow, inv_s);
+    const float zcn = zc[n];
     const int4* br = brect + (size_t)n * nrect;
     const float4* fr = frec + (size_t)n * F * 3;
     // union boxes containing the pixel (ascending); 4 independent loads in flight per round
@@ -927,7 +948,7 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
             make_face_rec(a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, r);
             ok = face_pixel_eval(r, ppx, ppy, e);
           }
-          fn(ok, e.pz, e.d, cur_ff);
+          fn(ok, e.pz - zcn, e.d, cur_ff);
         }
       } else {                      // pathological: walk every face
         for (int f0 = 0; f0 < F; f0 += 64) {
@@ -939,7 +960,7 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
             load_face_rec(fr + (size_t)ff * 3, r, box);
             if (box_contains(box, pcol, prow)) ok = face_pixel_eval(r, ppx, ppy, e);
           }
-          fn(ok, e.pz, e.d, ff);
+          fn(ok, e.pz - zcn, e.d, ff);
         }
       }
     };
@@ -1105,7 +1126,7 @@ __global__ void gpix_from_dsil_kernel(size_t total, const float* __restrict__ si
 // 5d: backward, face-parallel gather (deterministic, no atomics).  16 lanes per face sweep the face's
 // pixel box in 4x4 patches; d(signed dist^2)/d(vertex) flows through the nearest edge only.
 __global__ void __launch_bounds__(256)
-raster_bwd_kernel(int F, int S, const float4* __restrict__ frec, const float2* __restrict__ gz,
+raster_bwd_kernel(int F, int S, const float4* __restrict__ frec, const float* __restrict__ zc, const float2* __restrict__ gz,
                   float* __restrict__ dface /*[M][F][6]*/) {
   const int n = blockIdx.y;
   const int f = blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -1118,6 +1139,7 @@ raster_bwd_kernel(int F, int S, const float4* __restrict__ frec, const float2* _
     const int c0 = box.x & 0xffff, c1 = box.x >> 16, r0 = box.y & 0xffff, r1 = box.y >> 16;
     if (c0 <= c1) {
       const float inv_s = 1.0f / (float)S;
+      const float zcn = zc[n];
       const float2* gp = gz + (size_t)n * S * S;
       const int bw = c1 - c0 + 1, npx = bw * (r1 - r0 + 1);
       const float inv_bw = 1.0f / (float)bw;
@@ -1130,9 +1152,9 @@ raster_bwd_kernel(int F, int S, const float4* __restrict__ frec, const float2* _
           if (g.x == 0.f) continue;
           PixEval e;
           if (!face_pixel_eval(r, pix_to_ndc(col, inv_s), pix_to_ndc(row, inv_s), e)) continue;
-          if (e.pz > g.y) continue;                 // not among the pixel's K nearest
+          if (e.pz - zcn > g.y) continue;           // not among the pixel's K nearest
           // dL/dd = gpix * p ;  d = -+dist ;  d dist/d(u) = -2 q (1 - tc), d dist/d(w) = -2 q tc
-          const float gd = g.x * prob(e.d) * (e.inside ? -1.0f : 1.0f) * -2.0f;
+          const float gd = g.x * prob_fast(e.d) * (e.inside ? -1.0f : 1.0f) * -2.0f;
           const float ku = 1.0f - e.tc, kw = e.tc;
           const float ca = (e.edge == 2) ? 0.f : ku;
           const float cb = (e.edge == 0) ? kw : ((e.edge == 2) ? ku : 0.f);

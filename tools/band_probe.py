@@ -19,7 +19,7 @@ def main():
     e.set_shape_prior(*sp)
     W = np.array(config.OPT_WEIGHTS).T
     sched = bench.scaled_schedule(steps)
-    out = (ctypes.c_int * 4)()
+    out = (ctypes.c_int * 8)()
     for rep in range(2):                       # rep 0 = warm-up
         f = fit.FusedFitter(e, tj, vis, tsil, 8, True, sp[1][:20], sp[1][20:26])
         for stage_id, its in enumerate(sched):
@@ -38,6 +38,7 @@ def main():
                 bounded, hit, bsum = out[1], out[2], out[3]
                 print("stage %d its %4d  ms/it %.3f  bounded px/it %8.0f  hit %.3f  mean band %.1f  " %
                       (stage_id, its, dt * 1e3, bounded / its, hit / max(bounded, 1), bsum / max(hit, 1)),
+                      "miss c>K %.3f band-full %.3f short %.3f" % tuple(out[i] / max(bounded, 1) for i in (4, 5, 6)),
                       {k: round(v[0] / max(v[1], 1), 4) for k, v in sec.items()}, flush=True)
 
 
