@@ -34,6 +34,9 @@ SCHEDULE_ITERS = (150, 400, 600, 800)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+PROFILE_STRIDE = 8
+
+
 def scaled_schedule(total):
     """split `total` iterations over the 4 stages in the reference's 150:400:600:800 proportion"""
     raw = [total * s / float(sum(SCHEDULE_ITERS)) for s in SCHEDULE_ITERS]
@@ -165,7 +168,9 @@ def main():
     fitter = new_fitter()
     sched = scaled_schedule(args.steps)
     base = fitter.fitter if world > 1 else fitter
-    base.e.profile_begin(args.steps)
+    # HIP events on the launch stream inside the timed region, on every 8th iteration (an event record costs ~5 us
+    # of stream time; all sections of every iteration would slow the measured loop by ~8 %)
+    base.e.profile_begin(args.steps, PROFILE_STRIDE)
     sync()
     t0 = time.perf_counter()
     run(fitter, sched)

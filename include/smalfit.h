@@ -64,16 +64,18 @@ int smalfit_engine_status(smalfit_engine* engine, void* stream, int* status_bits
 int smalfit_engine_reset_raster_cache(smalfit_engine* engine, void* stream);
 
 /* optional: time sections of smalfit_fit_eval with HIP events recorded on the caller's stream.
- * profile_begin arms up to max_evals evaluations; profile_end synchronises `stream`, and returns the summed
- * milliseconds and the number of timed evaluations per section. */
+ * profile_begin arms up to max_evals timed evaluations, taking every `stride`-th evaluation (an event record costs
+ * ~5 us of stream time on MI355X, so timing every evaluation would slow the loop it measures by several percent);
+ * profile_end synchronises `stream`, and returns the summed milliseconds and the number of timed evaluations per
+ * section. */
 #define SMALFIT_NUM_SECTIONS 6
 #define SMALFIT_SEC_LBS_FWD 0        /* shape + pose + skin + joints kernels                     */
 #define SMALFIT_SEC_RASTER_SWEEP 1   /* accumulator memset + face_bbox_kernel + raster_sweep_kernel */
 #define SMALFIT_SEC_RASTER_SELECT 2  /* raster_select_kernel alone (K-nearest selection)          */
 #define SMALFIT_SEC_RASTER_BWD 3     /* raster_bwd_kernel alone                                   */
-#define SMALFIT_SEC_LBS_BWD 4        /* vertex / dA / pose-blend / chain adjoints                 */
-#define SMALFIT_SEC_RASTER_RESOLVE 5 /* raster_resolve_kernel alone                               */
-int smalfit_engine_profile_begin(smalfit_engine* engine, int max_evals);
+#define SMALFIT_SEC_LBS_BWD 4        /* vertex, mid-stage (dA, pose-blend, shape-blend) and chain adjoints */
+#define SMALFIT_SEC_RASTER_RESOLVE 5 /* raster_resolve_kernel + raster_band_kernel                  */
+int smalfit_engine_profile_begin(smalfit_engine* engine, int max_evals, int stride);
 int smalfit_engine_profile_end(smalfit_engine* engine, void* stream, float* ms_total, int* counts);
 
 /* replaces: Prior.__init__ data              reference smal_fitter/priors/pose_prior_35.py:51-92

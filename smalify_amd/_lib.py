@@ -54,7 +54,7 @@ SIGNATURES = {
     "smalfit_engine_destroy": (None, [_VP]),
     "smalfit_engine_status": (_I, [_VP, _VP, c_int_p]),
     "smalfit_engine_reset_raster_cache": (_I, [_VP, _VP]),
-    "smalfit_engine_profile_begin": (_I, [_VP, _I]),
+    "smalfit_engine_profile_begin": (_I, [_VP, _I, _I]),
     "smalfit_engine_profile_end": (_I, [_VP, _VP, _VP, _VP]),
     "smalfit_engine_set_pose_prior": (_I, [_VP, _VP, _VP, _VP]),
     "smalfit_engine_set_shape_prior": (_I, [_VP, _VP, _VP, _I]),

@@ -110,8 +110,9 @@ class Engine:
         """Forget the rasteriser's cached per-pixel depth bounds (affects time only, never results)."""
         check(self.lib.smalfit_engine_reset_raster_cache(self.handle, _stream()), "smalfit_engine_reset_raster_cache")
 
-    def profile_begin(self, max_evals):
-        check(self.lib.smalfit_engine_profile_begin(self.handle, int(max_evals)), "smalfit_engine_profile_begin")
+    def profile_begin(self, max_evals, stride=1):
+        """Time the sections of every `stride`-th fit_eval with HIP events on the launch stream (up to max_evals)."""
+        check(self.lib.smalfit_engine_profile_begin(self.handle, int(max_evals), int(stride)), "smalfit_engine_profile_begin")
 
     def profile_end(self):
         """-> {section: (total_ms, count)} measured with HIP events on the current stream."""

@@ -26,7 +26,7 @@ def main():
             f.begin_stage(stage_id)
             lib.smalfit_debug_set(ctypes.c_int(8 if os.environ.get('PROBE_STATS', '1') == '1' else 0))
             lib.smalfit_debug_stats(e.handle, out)
-            e.profile_begin(its)
+            e.profile_begin(its, int(os.environ.get('PROBE_STRIDE', '1')))
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(its):
                 f.step(W[stage_id][:6], float(W[stage_id][6]), float(W[stage_id][8]), stage_id)
