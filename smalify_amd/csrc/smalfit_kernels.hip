@@ -46,6 +46,35 @@ __device__ __forceinline__ float block_sum(float v, float* red /* >= 16 floats o
   return t;
 }
 
+// butterfly reduce-scatter: after folding with bits 32..1 every lane holds the wave-wide sums of two accumulators
+// (indices 2*lane, 2*lane+1) -- 126 shuffles instead of 128 full wave reductions; the summation order is fixed
+template <int HALF>
+__device__ __forceinline__ void fold_accumulators(float* acc, int lane, int bit) {
+#pragma unroll
+  for (int j = 0; j < HALF; ++j) {
+    const bool up = (lane & bit) != 0;
+    const float keep = up ? acc[HALF + j] : acc[j];
+    const float send = up ? acc[j] : acc[HALF + j];
+    acc[j] = keep + __shfl_xor(send, bit, 64);
+  }
+}
+
+// wave-wide sums of NV (16 or 32) per-lane values with a butterfly reduce-scatter: lane l returns the total of value
+// (l * NV) >> 6.  NV - 1 + log2(64 / NV) shuffles instead of 6 NV; fixed order.
+template <int NV>
+__device__ __forceinline__ float wave_sums(float* v, int lane) {
+  static_assert(NV == 16 || NV == 32, "16 or 32 values");
+  fold_accumulators<NV / 2>(v, lane, 32);
+  fold_accumulators<NV / 4>(v, lane, 16);
+  fold_accumulators<NV / 8>(v, lane, 8);
+  fold_accumulators<NV / 16>(v, lane, 4);
+  if (NV == 32) fold_accumulators<NV / 32>(v, lane, 2);
+  float r = v[0];
+  if (NV == 16) r += __shfl_xor(r, 2, 64);
+  r += __shfl_xor(r, 1, 64);
+  return r;
+}
+
 __device__ __forceinline__ int frame_window_size(int n, int M, int window) {
   // frames are grouped into consecutive windows of `window` frames, the last one may be ragged
   // (optimize_to_joints.py:119-120)
@@ -165,6 +194,115 @@ __global__ void build_theta_kernel(int M, const float* __restrict__ grot, const 
 // ------------------------------------------------------------------------------------------------
 // K2: pose blend + skinning + camera transform.  block = 64 vertices x FR frames, 4 waves split K=306
 // ------------------------------------------------------------------------------------------------
+// K1b (MFMA form): pose blend as a skinny GEMM on the matrix cores, then skinning + camera.
+//   blend[n][c] = sum_k pf[n][k] * pd[k][c]   (n: 16 frames, c: 16 vertices x {x,y,z}, k: 306 pose features)
+// One wave owns 16 vertices x 16 frames; v_mfma_f32_16x16x4_f32 (exact f32: an fmaf chain) takes
+// A[i = lane & 15][k = lane >> 4] = pfT[k][n0 + i] and B[k = lane >> 4][j = lane & 15] = pd[k][a][v0 + j], both read
+// straight from global memory as 64-byte segments; D[row = 4 (lane >> 4) + r][col = lane & 15], so a lane ends up with
+// x, y, z of ONE vertex for FOUR frames -- exactly what the skinning step needs.  77 k-steps x 3 MFMAs per wave.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256)
+skin_mfma_kernel(ModelDev m, int M, int Mp, const float* __restrict__ v_shaped, int vs_stride /*0 | 3*Vp*/,
+                 const float* __restrict__ pfT, const float* __restrict__ Am, const float* __restrict__ trans,
+                 float* __restrict__ vposed, float* __restrict__ verts, float* __restrict__ proj) {
+  __shared__ float As[16][420];
+  const int Vp = m.Vp;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n0 = blockIdx.y * 16;
+  const int v = blockIdx.x * 64 + w * 16 + (lane & 15);
+  const int kq = lane >> 4;
+  for (int i = threadIdx.x; i < 16 * 420; i += 256) {
+    const int f = i / 420;
+    As[f][i % 420] = (n0 + f < M) ? Am[(size_t)(n0 + f) * 420 + (i % 420)] : 0.f;
+  }
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
+  const float* pa = pfT + (size_t)kq * Mp + n0 + (lane & 15);
+  const float* pb = m.pd + (size_t)kq * 3 * Vp + v;
+  // 77 k-steps of 4 pose features (features 306, 307 do not exist: pfT has two zero rows there and the pd row is
+  // clamped, 0 * finite = 0).  With about one wave per SIMD nothing hides a load but the wave itself: operands are
+  // fetched a batch of 11 steps ahead (44 loads in flight) into two register sets used alternately.
+  constexpr int U = 11, NBATCH = 7;
+  static_assert(U * NBATCH == 77, "306 pose features in steps of 4");
+  float xa[U], x0[U], x1[U], x2[U], ya[U], y0[U], y1[U], y2[U];
+  auto load_batch = [&](int bt, float* A, float* B0, float* B1, float* B2) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int st = bt * U + u;
+      A[u] = pa[(size_t)st * 4 * Mp];
+      const float* b = pb + (size_t)(min(st * 4 + kq, 305) - kq) * 3 * Vp;
+      B0[u] = b[0]; B1[u] = b[Vp]; B2[u] = b[2 * Vp];
+    }
+  };
+  auto mfma_batch = [&](const float* A, const float* B0, const float* B1, const float* B2) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u], B0[u], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u], B1[u], acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u], B2[u], acc2, 0, 0, 0);
+    }
+  };
+  load_batch(0, xa, x0, x1, x2);
+  for (int bt = 0; bt < NBATCH - 1; bt += 2) {
+    load_batch(bt + 1, ya, y0, y1, y2);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_batch(xa, x0, x1, x2);
+    __builtin_amdgcn_sched_barrier(0);
+    load_batch(bt + 2, xa, x0, x1, x2);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_batch(ya, y0, y1, y2);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  mfma_batch(xa, x0, x1, x2);
+  __syncthreads();
+  // skinning weights of this lane's vertex (ELL), then its four frames
+  int wj[8];
+  float wv[8];
+  const int Kw = min(m.Kw, 8);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    wj[e] = (e < Kw) ? m.w_j[e * Vp + v] : 0;
+    wv[e] = (e < Kw) ? m.w_val[e * Vp + v] : 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int f = 4 * kq + r, n = n0 + f;
+    if (n >= M) break;
+    const float* vs = v_shaped + (size_t)n * vs_stride;
+    const float vp[3] = {vs[v] + acc0[r], vs[Vp + v] + acc1[r], vs[2 * Vp + v] + acc2[r]};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) vposed[((size_t)n * 3 + a) * Vp + v] = vp[a];
+    float T[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (e < Kw) {
+        const float* A = &As[f][wj[e] * 12];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) T[c] = fmaf(wv[e], A[c], T[c]);
+      }
+    }
+    for (int e = 8; e < m.Kw; ++e) {            // models with more than 8 weights per vertex
+      const int j = m.w_j[e * Vp + v];
+      const float wx = m.w_val[e * Vp + v];
+      const float* A = &As[f][j * 12];
+#pragma unroll
+      for (int c = 0; c < 12; ++c) T[c] = fmaf(wx, A[c], T[c]);
+    }
+    float o[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      o[a] = fmaf(T[a * 4], vp[0], fmaf(T[a * 4 + 1], vp[1], fmaf(T[a * 4 + 2], vp[2], T[a * 4 + 3])));
+      verts[((size_t)n * 3 + a) * Vp + v] = o[a];
+    }
+    float xn, yn, zv;
+    world_to_ndc(o[0] + trans[n * 3], o[1] + trans[n * 3 + 1], o[2] + trans[n * 3 + 2], xn, yn, zv);
+    proj[((size_t)n * 3 + 0) * Vp + v] = xn;
+    proj[((size_t)n * 3 + 1) * Vp + v] = yn;
+    proj[((size_t)n * 3 + 2) * Vp + v] = zv;
+  }
+}
+
 template <int FR>
 __global__ void __launch_bounds__(256)
 skin_kernel(ModelDev m, int M, int Mp, const float* __restrict__ v_shaped, int vs_stride /*0 | 3*Vp*/,
@@ -1277,13 +1415,13 @@ vertex_bwd_kernel(ModelDev m, int M, const float* __restrict__ proj, const float
 // K7: dA[n][j] = sum over the skin-weight column of joint j of  w * dvert (x) [v_posed; 1]
 __device__ __forceinline__ void
 dA_block(const ModelDev& m, int j, int n, const float* __restrict__ dvert, const float* __restrict__ vposed,
-         float* __restrict__ dA /*[M][35][12]*/, float* red) {
+         float* __restrict__ dA /*[M][35][12]*/, float (*part)[32]) {
   const int Vp = m.Vp;
   const float* dv = dvert + (size_t)n * 3 * Vp;
   const float* vp = vposed + (size_t)n * 3 * Vp;
-  float acc[12];
+  float acc[16];
 #pragma unroll
-  for (int e = 0; e < 12; ++e) acc[e] = 0.f;
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   for (int i = m.wc_off[j] + threadIdx.x; i < m.wc_off[j + 1]; i += 256) {
     const int v = m.wc_v[i];
     const float wv = m.wc_val[i];
@@ -1295,30 +1433,18 @@ dA_block(const ModelDev& m, int j, int n, const float* __restrict__ dvert, const
       for (int b = 0; b < 4; ++b) acc[a * 4 + b] = fmaf(d, p[b], acc[a * 4 + b]);
     }
   }
-#pragma unroll
-  for (int e = 0; e < 12; ++e) {
-    const float s = block_sum(acc[e], red);
-    if (threadIdx.x == 0) dA[((size_t)n * 35 + j) * 12 + e] = s;
-  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float tot = wave_sums<16>(acc, lane);           // value lane >> 2
+  if ((lane & 3) == 0) part[w][lane >> 2] = tot;
+  __syncthreads();
+  if (threadIdx.x < 12)
+    dA[((size_t)n * 35 + j) * 12 + threadIdx.x] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
 }
 
 // K8: pose-blend adjoint  dpf[n][k] = sum_col dvp[n][col] * pd[k][col]   (split over columns)
 // one wave = 16 frames x 8 pose features, lanes stride the 3*Vp columns of its column split.
 constexpr int PB_NT = 8, PB_KT = 8;
 constexpr int kAsmElem = 4, kAsmLoss = 16;   // assemble_kernel: blocks for element-wise gradients / loss partial sums
-// butterfly reduce-scatter: after folding with bits 32..1 every lane holds the wave-wide sums of two accumulators
-// (indices 2*lane, 2*lane+1) -- 126 shuffles instead of 128 full wave reductions; the summation order is fixed
-template <int HALF>
-__device__ __forceinline__ void fold_accumulators(float* acc, int lane, int bit) {
-#pragma unroll
-  for (int j = 0; j < HALF; ++j) {
-    const bool up = (lane & bit) != 0;
-    const float keep = up ? acc[HALF + j] : acc[j];
-    const float send = up ? acc[j] : acc[HALF + j];
-    acc[j] = keep + __shfl_xor(send, bit, 64);
-  }
-}
-
 // one wave: PB_NT frames x PB_KT pose features over one column split
 __device__ __forceinline__ void
 poseblend_bwd_wave(const ModelDev& m, int M, int CS, int kx, int ny, int cs, int lane, const float* __restrict__ dvp,
@@ -1370,7 +1496,7 @@ poseblend_bwd_wave(const ModelDev& m, int M, int CS, int kx, int ny, int cs, int
 //     per-frame betas (blockIdx.y = frame): no sum over frames.
 __device__ __forceinline__ void
 dbeta_block(const ModelDev& m, int M, int nb, int shared, int bx, int by, int bz, int gx, int gzn,
-            const float* __restrict__ dvp, float* __restrict__ dbeta_part /*[nbs][gzn * gx][nb]*/, float* red) {
+            const float* __restrict__ dvp, float* __restrict__ dbeta_part /*[nbs][gzn * gx][nb]*/, float (*part)[32]) {
   const int ncol = 3 * m.Vp;
   const int c = bx * 256 + threadIdx.x;
   float g = 0.f;
@@ -1383,10 +1509,84 @@ dbeta_block(const ModelDev& m, int M, int nb, int shared, int bx, int by, int bz
       g = dvp[(size_t)by * ncol + c];
     }
   }
-  const size_t part = (size_t)by * gzn * gx + (size_t)bz * gx + bx;
-  for (int b = 0; b < nb; ++b) {
-    const float s = block_sum((c < ncol) ? g * m.sd[(size_t)b * ncol + c] : 0.f, red);
-    if (threadIdx.x == 0) dbeta_part[part * nb + b] = s;
+  const size_t pidx = (size_t)by * gzn * gx + (size_t)bz * gx + bx;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int b0 = 0; b0 < nb; b0 += 32) {                 // shape directions in groups of 32
+    float val[32];
+#pragma unroll
+    for (int b = 0; b < 32; ++b) val[b] = (c < ncol && b0 + b < nb) ? g * m.sd[(size_t)(b0 + b) * ncol + c] : 0.f;
+    const float tot = wave_sums<32>(val, lane);         // value lane >> 1
+    __syncthreads();
+    if ((lane & 1) == 0) part[w][lane >> 1] = tot;
+    __syncthreads();
+    if (threadIdx.x < 32 && b0 + threadIdx.x < nb)
+      dbeta_part[pidx * nb + b0 + threadIdx.x] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+  }
+}
+
+// pose-blend adjoint on the matrix cores:  dpf[n][k] = sum_c dvp[n][c] * pd[k][c]  (c: the 3 Vp columns).
+// A block owns 16 frames x 32 pose features and one of PBM_SPLITS column ranges; its four waves take a quarter of
+// the range each and their tiles are added through LDS in a fixed order.  Both operands are rows of length 3 Vp, so
+// a lane fetches FOUR consecutive columns (one 16-byte load; 16 rows x 64 bytes per instruction) and the four
+// v_mfma_f32_16x16x4_f32 that follow pair component i of A with component i of B: the instruction only needs A and B
+// to agree on which column sits in which k slot.
+constexpr int PBM_SPLITS = 6, PBM_U = 4;
+__device__ __forceinline__ void
+poseblend_bwd_mfma_block(const ModelDev& m, int M, int ftile, int kpair, int split, const float* __restrict__ dvp,
+                         float* __restrict__ dpf_part /*[PBM_SPLITS][M][308]*/, float (*red)[8][64]) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int ncol = 3 * m.Vp, nsteps = ncol / 16;            // Vp is a multiple of 64
+  const int per = (nsteps + PBM_SPLITS * 4 - 1) / (PBM_SPLITS * 4);
+  const int s_beg = (split * 4 + w) * per, s_end = min(nsteps, s_beg + per);
+  const int n0 = ftile * 16, k0 = kpair * 32;
+  const int row = lane & 15, cq = (lane >> 4) * 4;
+  const float4* pa = reinterpret_cast<const float4*>(dvp + (size_t)min(n0 + row, M - 1) * ncol + cq);
+  const float4* pb0 = reinterpret_cast<const float4*>(m.pd + (size_t)min(k0 + row, 305) * ncol + cq);
+  const float4* pb1 = reinterpret_cast<const float4*>(m.pd + (size_t)min(k0 + 16 + row, 305) * ncol + cq);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  float4 xa[PBM_U], x0[PBM_U], x1[PBM_U], ya[PBM_U], y0[PBM_U], y1[PBM_U];
+  auto load_batch = [&](int st0, float4* A, float4* B0, float4* B1) {
+#pragma unroll
+    for (int u = 0; u < PBM_U; ++u) {
+      const int st = min(st0 + u, nsteps - 1);               // past the end: a valid address, zeroed below
+      A[u] = pa[st * 4]; B0[u] = pb0[st * 4]; B1[u] = pb1[st * 4];
+      if (st0 + u >= s_end) A[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto mfma_batch = [&](const float4* A, const float4* B0, const float4* B1) {
+#pragma unroll
+    for (int u = 0; u < PBM_U; ++u) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u].x, B0[u].x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u].x, B1[u].x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u].y, B0[u].y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u].y, B1[u].y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u].z, B0[u].z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u].z, B1[u].z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u].w, B0[u].w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u].w, B1[u].w, acc1, 0, 0, 0);
+    }
+  };
+  load_batch(s_beg, xa, x0, x1);
+  for (int st = s_beg; st < s_end; st += 2 * PBM_U) {
+    load_batch(st + PBM_U, ya, y0, y1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_batch(xa, x0, x1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_batch(st + 2 * PBM_U, xa, x0, x1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_batch(ya, y0, y1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { red[w][r][lane] = acc0[r]; red[w][4 + r][lane] = acc1[r]; }
+  __syncthreads();
+  // D[row = 4 (lane >> 4) + r][col = lane & 15]; wave t finishes registers 2t, 2t+1 of the eight
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int reg = w * 2 + q, r = reg & 3, tile = reg >> 2;
+    const float tot = ((red[0][reg][lane] + red[1][reg][lane]) + red[2][reg][lane]) + red[3][reg][lane];
+    const int n = n0 + 4 * (lane >> 4) + r, k = k0 + tile * 16 + (lane & 15);
+    if (n < M && k < 306) dpf_part[((size_t)split * M + n) * 308 + k] = tot;
   }
 }
 
@@ -1397,19 +1597,19 @@ __global__ void __launch_bounds__(256)
 lbs_bwd_mid_kernel(ModelDev m, int M, int CS, int nb, int betas_shared, int nPB, int nDB_x, int nDB_y, int nDB_z,
                    const float* __restrict__ dvert, const float* __restrict__ vposed, const float* __restrict__ dvp,
                    float* __restrict__ dA, float* __restrict__ dpf_part, float* __restrict__ dbeta_part) {
-  __shared__ float red[16];
+  __shared__ float part[4][32];
+  __shared__ float tile_red[4][8][64];
   int blk = blockIdx.x;
   if (blk < nPB) {
-    const int nkx = (306 + PB_KT - 1) / PB_KT, nny = (M + PB_NT - 1) / PB_NT;
-    const int vb = blk * 4 + (threadIdx.x >> 6);
-    if (vb < nkx * nny * CS) poseblend_bwd_wave(m, M, CS, vb % nkx, (vb / nkx) % nny, vb / (nkx * nny), threadIdx.x & 63, dvp, dpf_part);
+    const int nft = (M + 15) / 16;
+    poseblend_bwd_mfma_block(m, M, blk % nft, (blk / nft) % 10, blk / (nft * 10), dvp, dpf_part, tile_red);
     return;
   }
   blk -= nPB;
-  if (blk < 35 * M) { dA_block(m, blk % 35, blk / 35, dvert, vposed, dA, red); return; }
+  if (blk < 35 * M) { dA_block(m, blk % 35, blk / 35, dvert, vposed, dA, part); return; }
   blk -= 35 * M;
   if (blk < nDB_x * nDB_y * nDB_z)
-    dbeta_block(m, M, nb, betas_shared, blk % nDB_x, (blk / nDB_x) % nDB_y, blk / (nDB_x * nDB_y), nDB_x, nDB_z, dvp, dbeta_part, red);
+    dbeta_block(m, M, nb, betas_shared, blk % nDB_x, (blk / nDB_x) % nDB_y, blk / (nDB_x * nDB_y), nDB_x, nDB_z, dvp, dbeta_part, part);
 }
 
 // ------------------------------------------------------------------------------------------------

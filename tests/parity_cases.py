@@ -79,7 +79,7 @@ def case_rodrigues():
 
 def case_lbs(M=3, dense=False, with_scale=True):
     md, om, _ = get_model(dense)
-    e, _, _ = get_engine(8, 64, dense)
+    e, _, _ = get_engine(8 if M <= 8 else 24, 64, dense)
     rs = np.random.RandomState(5)
     beta = (0.5 * rs.randn(M, 20)).astype(np.float32)
     theta = (0.3 * rs.randn(M, 35, 3)).astype(np.float32)

@@ -33,9 +33,10 @@ def test_adam():
     assert pc.case_adam()["adam_rel"] < 1e-6
 
 
-@pytest.mark.parametrize("dense,with_scale", [(False, True), (True, False)])
-def test_lbs_forward_backward(dense, with_scale):
-    m = pc.case_lbs(3, dense, with_scale)
+@pytest.mark.parametrize("M,dense,with_scale", [(3, False, True), (3, True, False), (21, False, True)])
+def test_lbs_forward_backward(M, dense, with_scale):
+    """M = 21 takes the matrix-core pose-blend kernel (frames in tiles of 16, the second tile ragged)"""
+    m = pc.case_lbs(M, dense, with_scale)
     for k in ("lbs_verts_rel", "lbs_joints_rel", "lbs_Rs_rel", "lbs_vshaped_rel"):
         assert m[k] < 2e-5, (k, m[k])
     for k in ("lbs_dbeta_rel", "lbs_dtheta_rel") + (("lbs_dlogscale_rel",) if with_scale else ()):
