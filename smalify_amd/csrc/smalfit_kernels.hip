@@ -654,7 +654,7 @@ __device__ __forceinline__ float prob_fast(float d) {
 __global__ void __launch_bounds__(256)
 face_bbox_kernel(ModelDev m, int S, const float* __restrict__ proj, int2* __restrict__ fbox,
                  float4* __restrict__ frec /*[M][F][3]*/, int4* __restrict__ brect /*[M][ceil(F/32)]*/,
-                 float* __restrict__ zc /*[M]*/) {
+                 float* __restrict__ zc /*[M]*/, int* __restrict__ frect /*[M][4]: S - x0, x1 + 1, S - y0, y1 + 1 of the active region; 0 = empty*/) {
   const int f = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
   const int Vp = m.Vp;
   const float* px = proj + (size_t)n * 3 * Vp;
@@ -707,6 +707,33 @@ face_bbox_kernel(ModelDev m, int S, const float* __restrict__ proj, int2* __rest
   }
   if ((threadIdx.x & (kRectFaces - 1)) == 0 && f < m.F)
     brect[(size_t)n * ((m.F + kRectFaces - 1) / kRectFaces) + f / kRectFaces] = make_int4(x0, x1, y0, y1);
+  // the frame's active region: pixel box of ALL projected vertices, blur-expanded -- a superset of every face box, so
+  // pixels outside it have no candidate at all.  Block 0 of the frame scans the vertices (no atomics).
+  if (blockIdx.x == 0) {
+    __shared__ float rr[4][4];
+    float xlo = 3.0e38f, xhi = -3.0e38f, ylo = 3.0e38f, yhi = -3.0e38f;
+    for (int v = threadIdx.x; v < m.V; v += 256) {
+      const float x = px[v], y = px[Vp + v];
+      xlo = fminf(xlo, x); xhi = fmaxf(xhi, x); ylo = fminf(ylo, y); yhi = fmaxf(yhi, y);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      xlo = fminf(xlo, __shfl_xor(xlo, o, 64)); xhi = fmaxf(xhi, __shfl_xor(xhi, o, 64));
+      ylo = fminf(ylo, __shfl_xor(ylo, o, 64)); yhi = fmaxf(yhi, __shfl_xor(yhi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { float* q = rr[threadIdx.x >> 6]; q[0] = xlo; q[1] = xhi; q[2] = ylo; q[3] = yhi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; ++w) { xlo = fminf(xlo, rr[w][0]); xhi = fmaxf(xhi, rr[w][1]); ylo = fminf(ylo, rr[w][2]); yhi = fmaxf(yhi, rr[w][3]); }
+      xlo -= kBlurSqrt; xhi += kBlurSqrt; ylo -= kBlurSqrt; yhi += kBlurSqrt;
+      const float fs = (float)S;
+      const float c0 = fmaxf(floorf(((1.0f - xhi) * fs - 1.0f) * 0.5f), 0.f), c1 = fminf(ceilf(((1.0f - xlo) * fs - 1.0f) * 0.5f), fs - 1.f);
+      const float r0 = fmaxf(floorf(((1.0f - yhi) * fs - 1.0f) * 0.5f), 0.f), r1 = fminf(ceilf(((1.0f - ylo) * fs - 1.0f) * 0.5f), fs - 1.f);
+      int4 o = make_int4(0, 0, 0, 0);              // (S - c0, c1 + 1, S - r0, r1 + 1); zeros = empty
+      if (c0 <= c1 && r0 <= r1) o = make_int4(S - (int)c0, (int)c1 + 1, S - (int)r0, (int)r1 + 1);
+      *reinterpret_cast<int4*>(frect + n * 4) = o;
+    }
+  }
 }
 
 __device__ __forceinline__ bool load_face_rec(const float4* __restrict__ fr, FaceRec& r, int2& box) {
@@ -829,8 +856,8 @@ raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, const float* 
 // raster_resolve_kernel is thread-per-pixel: it finishes the pixels that need no sorting and appends the others to
 // the band queue or the select queue (one global atomic per block and queue).
 __global__ void __launch_bounds__(256)
-raster_resolve_kernel(int S, int M, int window, float w_sil, const unsigned long long* __restrict__ gacc,
-                      const unsigned* __restrict__ bcnt, const float2* __restrict__ zband,
+raster_resolve_kernel(int S, int M, int window, float w_sil, unsigned long long* __restrict__ gacc,
+                      unsigned* __restrict__ bcnt, const int* __restrict__ frect, const float2* __restrict__ zband,
                       const float* __restrict__ tsil, float* __restrict__ sil_out,
                       float2* __restrict__ gz, float* __restrict__ blk_loss, int* __restrict__ qcount /*[0] select, [1] band*/,
                       int* __restrict__ queue, int* __restrict__ bqueue, int* __restrict__ stats /*developer counters or null*/) {
@@ -850,7 +877,14 @@ raster_resolve_kernel(int S, int M, int window, float w_sil, const unsigned long
   __syncthreads();
   int action = 0, slot = 0;                        // 0: finished from the sum alone, 1: select queue, 2: band queue
   float l = 0.f;
-  if (inimg) {
+  // tiles outside the frame's active region hold no candidate: silhouette 0, nothing else to read or write
+  const int4 fr = *reinterpret_cast<const int4*>(frect + n * 4);
+  const bool active = fr.y > 0 && tx * 16 <= fr.y - 1 && tx * 16 + 15 >= S - fr.x && ty * 16 <= fr.w - 1 && ty * 16 + 15 >= S - fr.z;
+  if (inimg && !active) {
+    if (sil_out) sil_out[pi] = 0.f;
+    if (tsil) l = fabsf(tsil[pi]);
+  }
+  if (inimg && active) {
     const unsigned long long vb = gacc[pi];
     const int c = (int)(vb >> kCountShift);
     const int b = (int)bcnt[pi];
@@ -882,6 +916,11 @@ raster_resolve_kernel(int S, int M, int window, float w_sil, const unsigned long
     } else {
       slot = atomicAdd(&qn[action - 1], 1);
     }
+    // the accumulators are left zero for the next sweep by whoever reads them last (band pixels: raster_band_kernel)
+    if (action != 2) {
+      if (vb) gacc[pi] = 0ull;
+      if (b) bcnt[pi] = 0u;
+    }
   }
   __syncthreads();
   if (t < 2) qbase[t] = qn[t] > 0 ? atomicAdd(&qcount[t], qn[t]) : 0;
@@ -898,8 +937,8 @@ raster_resolve_kernel(int S, int M, int window, float w_sil, const unsigned long
 // rank by counting against an LDS broadcast of the 32 depths, include the K - c nearest, check for a tie at the cut.
 constexpr int kBandBlocks = 1024;
 __global__ void __launch_bounds__(256)
-raster_band_kernel(int S, int M, int window, float w_sil, const unsigned long long* __restrict__ gacc,
-                   const unsigned* __restrict__ bcnt, const float2* __restrict__ blist,
+raster_band_kernel(int S, int M, int window, float w_sil, unsigned long long* __restrict__ gacc,
+                   unsigned* __restrict__ bcnt, const float2* __restrict__ blist,
                    const float* __restrict__ tsil, float* __restrict__ sil_out, float2* __restrict__ gz,
                    int* __restrict__ qcount, int* __restrict__ queue, const int* __restrict__ bqueue,
                    float* __restrict__ bloss /*[gridDim.x]: weighted |sil - target| per block, or null*/) {
@@ -922,6 +961,7 @@ raster_band_kernel(int S, int M, int window, float w_sil, const unsigned long lo
     float2 v = make_float2(kInf, 0.f);
     if (hl < b) v = blist[pi * kBandCap + hl];
     const int need = min(K - (int)(vb >> kCountShift), b);
+    if (hl == 0) { gacc[pi] = 0ull; bcnt[pi] = 0u; }        // zero for the next sweep
     zs[hw][hl] = v.x;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
