@@ -611,13 +611,22 @@ shape_prior_kernel(const float* __restrict__ betas, const float* __restrict__ lo
 //              The largest included depth (zthr) is stored so that raster_bwd_kernel truncates identically.
 // ------------------------------------------------------------------------------------------------
 constexpr int kRectFaces = 8;             // faces per entry of the union-box index
-constexpr int kSweepFaces = 128;          // faces per sweep block
-constexpr int kAccWin = 48;               // LDS accumulator window edge (pixels); outside: global atomics
+#ifndef SMALFIT_SWEEP_FACES
+#define SMALFIT_SWEEP_FACES 32
+#endif
+#ifndef SMALFIT_ACC_WIN
+#define SMALFIT_ACC_WIN 32
+#endif
+constexpr int kSweepFaces = SMALFIT_SWEEP_FACES;   // faces per sweep block
+constexpr int kAccWin = SMALFIT_ACC_WIN;  // LDS accumulator window edge (pixels); outside: global atomics
 constexpr int kCountShift = 50;
 constexpr float kLogFix = 16777216.0f;    // 2^24
 constexpr int kBandCap = 32;              // per-pixel list of candidates between the two cached depth bounds
 constexpr int kBandFill = 24;             // the select kernel sizes the band to hold at most this many entries
-constexpr int kBandStage = 128;           // band entries staged per wave in the sweep before a batched append
+#ifndef SMALFIT_BAND_STAGE
+#define SMALFIT_BAND_STAGE 128
+#endif
+constexpr int kBandStage = SMALFIT_BAND_STAGE;   // band entries staged per wave in the sweep before a batched append
 constexpr float kBandHalf = 8.0f;         // initial half-width of the band, in mean depth gaps of the K nearest
 
 __device__ __forceinline__ unsigned orderable(float f) {
