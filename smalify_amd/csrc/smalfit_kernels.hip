@@ -1052,7 +1052,12 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
   const int nrect = (F + kRectFaces - 1) / kRectFaces;
   const float inv_s = 1.0f / (float)S;
   const int npix = S * S;
-  for (int qi = blockIdx.x * kSelWaves + w; qi < nq; qi += gridDim.x * kSelWaves) {
+  // XCD-affine split of the queue: workgroups are dealt to the 8 XCDs round-robin, and the queue is roughly
+  // frame-ordered (resolve blocks of a frame append together), so XCD x takes the x-th eighth of it and its L2 only
+  // has to hold the face records of ~M/8 frames instead of all of them.
+  const int xcd = blockIdx.x & 7, nbx = (gridDim.x + 7 - xcd) >> 3;       // blocks on this XCD (grid >= 8)
+  const int q_lo = (int)(((long long)nq * xcd) >> 3), q_hi = (int)(((long long)nq * (xcd + 1)) >> 3);
+  for (int qi = q_lo + (blockIdx.x >> 3) * kSelWaves + w; qi < q_hi; qi += nbx * kSelWaves) {
     const int gp = queue[qi];
     const int n = gp / npix, pix = gp % npix;
     const int pcol = pix % S, prow = pix / S;
@@ -1152,129 +1157,163 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
       }
     };
     int nc = 0;
+    const float kInf = __int_as_float(0x7f800000);
+    float zmn = kInf, zmx = -kInf;                      // depth range of the candidates
     scan_candidates([&](bool ok, float pz, float d, int ff) {
+      (void)ff;
       const unsigned long long bal = __ballot(ok);
       if (ok) {
         const int pos = nc + __popcll(bal & ((1ull << lane) - 1ull));
         if (pos < kCandCap) cand[w][pos] = make_float2(pz, one_minus_prob(d));
+        zmn = fminf(zmn, pz); zmx = fmaxf(zmx, pz);
       }
       nc += __popcll(bal);
     });
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { zmn = fminf(zmn, __shfl_xor(zmn, o, 64)); zmx = fmaxf(zmx, __shfl_xor(zmx, o, 64)); }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (dbg & 4) continue;
     const bool cached = nc <= kCandCap;
-    unsigned prefix = (nc <= K) ? 0xffffffffu : 0u;      // at most K candidates: keep them all, threshold +inf
-    int need = K;
-    for (int pass = 0; pass < ((nc <= K) ? 0 : 4); ++pass) {
-      const int shift = 24 - 8 * pass;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) hist[w][lane * 4 + i] = 0u;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+    // visit every candidate wave-wide: fn(valid, depth, 1 - p); from LDS, or by re-evaluation when they did not fit
+    auto visit = [&](auto&& fn) {
       if (cached) {
 #pragma unroll 4
         for (int i = 0; i < RC; ++i) {
           const int j = lane + 64 * i;
-          if (j < nc) {
-            const unsigned kk = orderable(cand[w][j].x);
-            if ((pass == 0) || ((kk >> (shift + 8)) == (prefix >> (shift + 8)))) atomicAdd(&hist[w][(kk >> shift) & 255u], 1u);
-          }
+          if (64 * i >= nc) break;
+          const float2 ev = (j < nc) ? cand[w][j] : make_float2(0.f, 1.f);
+          fn(j < nc, ev.x, ev.y);
         }
       } else {
-        scan_candidates([&](bool ok, float pz, float d, int ff) {
-          (void)d; (void)ff;
-          const unsigned kk = orderable(pz);
-          const bool in = ok && ((pass == 0) || ((kk >> (shift + 8)) == (prefix >> (shift + 8))));
-          if (in) atomicAdd(&hist[w][(kk >> shift) & 255u], 1u);
-        });
+        scan_candidates([&](bool ok, float pz, float d, int ff) { (void)ff; fn(ok, pz, ok ? one_minus_prob(d) : 1.0f); });
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const unsigned h0 = hist[w][lane * 4], h1 = hist[w][lane * 4 + 1], h2 = hist[w][lane * 4 + 2], h3 = hist[w][lane * 4 + 3];
-      const int s4 = (int)(h0 + h1 + h2 + h3);
-      int incl = s4;
+    };
+    // ---- depth of the K-th nearest: histogram over a linear quantisation of the current depth range (monotone, so the
+    // K-th lies in the bin where the running count crosses K), narrowed until that bin holds at most 64 candidates,
+    // which are then ranked exactly.  Usually one histogram pass.
+    float zk = kInf;
+    if (nc > K) {
+      float rlo = zmn, rhi = zmx;
+      int need = K;
+      float* sel = reinterpret_cast<float*>(&hist[w][0]);
+      for (int round = 0; round < 64; ++round) {
+        if (!(rhi > rlo)) { zk = rlo; break; }            // everything left has the same depth
+        const float scale = 256.0f / (rhi - rlo);
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int v = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += v;
+        for (int i = 0; i < 4; ++i) hist[w][lane * 4 + i] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        visit([&](bool ok, float z, float omp) {
+          (void)omp;
+          if (ok && z >= rlo && z <= rhi) atomicAdd(&hist[w][min(255, (int)((z - rlo) * scale))], 1u);
+        });
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned h0 = hist[w][lane * 4], h1 = hist[w][lane * 4 + 1], h2 = hist[w][lane * 4 + 2], h3 = hist[w][lane * 4 + 3];
+        const int s4 = (int)(h0 + h1 + h2 + h3);
+        int incl = s4;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int v = __shfl_up(incl, d, 64);
+          if (lane >= d) incl += v;
+        }
+        const int excl = incl - s4;
+        const bool mine = (excl < need) && (need <= incl);
+        int digit = 0, below = 0, cnt = 0;
+        if (mine) {
+          int cm = excl;
+          if (cm + (int)h0 >= need) { digit = lane * 4; below = cm; cnt = (int)h0; }
+          else { cm += (int)h0;
+            if (cm + (int)h1 >= need) { digit = lane * 4 + 1; below = cm; cnt = (int)h1; }
+            else { cm += (int)h1;
+              if (cm + (int)h2 >= need) { digit = lane * 4 + 2; below = cm; cnt = (int)h2; }
+              else { cm += (int)h2; digit = lane * 4 + 3; below = cm; cnt = (int)h3; } } }
+        }
+        const unsigned long long balm = __ballot(mine);
+        const int srcl = __ffsll((long long)balm) - 1;
+        digit = __shfl(digit, srcl, 64);
+        below = __shfl(below, srcl, 64);
+        cnt = __shfl(cnt, srcl, 64);
+        need -= below;
+        __builtin_amdgcn_wave_barrier();
+        if (cnt <= 64) {
+          // the bin's members into sel[] (the histogram is no longer needed), then exact ranks
+          int ns = 0;
+          visit([&](bool ok, float z, float omp) {
+            (void)omp;
+            const bool in = ok && z >= rlo && z <= rhi && min(255, (int)((z - rlo) * scale)) == digit;
+            const unsigned long long bal = __ballot(in);
+            if (in) sel[ns + __popcll(bal & ((1ull << lane) - 1ull))] = z;
+            ns += __popcll(bal);
+          });
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          const float key = (lane < ns) ? sel[lane] : kInf;
+          int rank = 0;
+          for (int q = 0; q < ns; ++q) { const float o = sel[q]; rank += (o < key || (o == key && q < lane)) ? 1 : 0; }
+          const unsigned long long balk = __ballot(lane < ns && rank == need - 1);
+          zk = __shfl(key, __ffsll((long long)balk) - 1, 64);
+          __builtin_amdgcn_wave_barrier();
+          break;
+        }
+        // narrow the range to the members of that bin
+        float nlo = kInf, nhi = -kInf;
+        visit([&](bool ok, float z, float omp) {
+          (void)omp;
+          if (ok && z >= rlo && z <= rhi && min(255, (int)((z - rlo) * scale)) == digit) { nlo = fminf(nlo, z); nhi = fmaxf(nhi, z); }
+        });
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { nlo = fminf(nlo, __shfl_xor(nlo, o, 64)); nhi = fmaxf(nhi, __shfl_xor(nhi, o, 64)); }
+        rlo = nlo; rhi = nhi;
       }
-      const int excl = incl - s4;
-      const bool mine = (excl < need) && (need <= incl);
-      int digit = 0, below = 0;
-      if (mine) {
-        int cm = excl;
-        if (cm + (int)h0 >= need) { digit = lane * 4; below = cm; }
-        else { cm += (int)h0;
-          if (cm + (int)h1 >= need) { digit = lane * 4 + 1; below = cm; }
-          else { cm += (int)h1;
-            if (cm + (int)h2 >= need) { digit = lane * 4 + 2; below = cm; }
-            else { cm += (int)h2; digit = lane * 4 + 3; below = cm; } } }
-      }
-      const unsigned long long balm = __ballot(mine);
-      const int srcl = __ffsll((long long)balm) - 1;
-      digit = __shfl(digit, srcl, 64);
-      below = __shfl(below, srcl, 64);
-      need -= below;
-      prefix |= ((unsigned)digit) << shift;
-      __builtin_amdgcn_wave_barrier();
     }
-    float a = 1.0f;
-    if (cached) {
-#pragma unroll 4
-      for (int i = 0; i < RC; ++i) {
-        const int j = lane + 64 * i;
-        if (j < nc) { const float2 ev = cand[w][j]; if (orderable(ev.x) <= prefix) a *= ev.y; }
+    // ---- one pass: product of the included factors, the nearest depth beyond the K-th, and the band population
+    // for kBandTries candidate half-widths (delta, delta/2, delta/4, ...)
+    constexpr int kBandTries = 6;
+    const float delta0 = (nc > K) ? kBandHalf * (zk - zmn) * (1.0f / (float)K) : 0.f;
+    float a = 1.0f, znext = kInf;
+    int cbs[kBandTries], cfs[kBandTries];
+#pragma unroll
+    for (int i = 0; i < kBandTries; ++i) { cbs[i] = 0; cfs[i] = 0; }
+    visit([&](bool ok, float z, float omp) {
+      if (ok) {
+        if (z <= zk) a *= omp; else znext = fminf(znext, z);
+        float dl = delta0;
+#pragma unroll
+        for (int i = 0; i < kBandTries; ++i) {
+          cbs[i] += (z > zk - dl && z <= zk + dl) ? 1 : 0;
+          cfs[i] += (z > zk + dl) ? 1 : 0;
+          dl *= 0.5f;
+        }
       }
-    } else {
-      scan_candidates([&](bool ok, float pz, float d, int ff) { (void)ff; if (ok && orderable(pz) <= prefix) a *= one_minus_prob(d); });
-    }
+    });
     a = wave_prod(a);
-    // depth of the K-th nearest, the nearest beyond it, and the nearest of all
-    unsigned nextk = 0xffffffffu, mink = 0xffffffffu;
-    if (cached) {
-#pragma unroll 4
-      for (int i = 0; i < RC; ++i) {
-        const int j = lane + 64 * i;
-        if (j < nc) { const unsigned kk = orderable(cand[w][j].x); mink = min(mink, kk); if (kk > prefix) nextk = min(nextk, kk); }
-      }
-    } else {
-      scan_candidates([&](bool ok, float pz, float d, int ff) { (void)d; (void)ff; const unsigned kk = orderable(pz); if (ok) { mink = min(mink, kk); if (kk > prefix) nextk = min(nextk, kk); } });
-    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      nextk = min(nextk, (unsigned)__shfl_xor((int)nextk, o, 64));
-      mink = min(mink, (unsigned)__shfl_xor((int)mink, o, 64));
+      znext = fminf(znext, __shfl_xor(znext, o, 64));
+#pragma unroll
+      for (int i = 0; i < kBandTries; ++i) { cbs[i] += __shfl_xor(cbs[i], o, 64); cfs[i] += __shfl_xor(cfs[i], o, 64); }
     }
-    const float kInf = __int_as_float(0x7f800000);
-    const float zk = (nc <= K) ? kInf : from_orderable(prefix);
     // backward threshold: midway between the K-th and the (K+1)-th nearest depth
     float zmid = zk;
-    if (nc > K && nextk != 0xffffffffu) {
-      const float zn = from_orderable(nextk);
-      zmid = 0.5f * (zk + zn);
-      if (!(zmid >= zk && zmid < zn)) zmid = zk;
+    if (nc > K && znext < kInf) {
+      zmid = 0.5f * (zk + znext);
+      if (!(zmid >= zk && zmid < znext)) zmid = zk;
     }
     // bounds for the next evaluations: lo < K-th <= hi, the band (lo, hi] sized to at most kBandFill candidates, so
     // that the K nearest stay provable from counts while depths drift by up to the band's half-width
     float blo = kInf, bhi = kInf;
     if (nc > K) {
       blo = bhi = zmid;
-      if (cached) {
-        float delta = kBandHalf * (zk - from_orderable(mink)) * (1.0f / (float)K);
-        for (int it = 0; it < 5 && delta > 0.f; ++it) {
-          const float lo = zk - delta, hi = zk + delta;
-          int cb = 0, cfar = 0;
-#pragma unroll 4
-          for (int i = 0; i < RC; ++i) {
-            const int j = lane + 64 * i;
-            if (j < nc) { const float z = cand[w][j].x; cb += (z > lo && z <= hi) ? 1 : 0; cfar += (z > hi) ? 1 : 0; }
-          }
+      float delta = delta0;
+      bool chosen = false;
 #pragma unroll
-          for (int o = 32; o > 0; o >>= 1) { cb += __shfl_xor(cb, o, 64); cfar += __shfl_xor(cfar, o, 64); }
-          if (cb <= kBandFill && lo < zk) { blo = lo; bhi = (cfar == 0) ? kInf : hi; break; }
-          delta *= 0.5f;
+      for (int i = 0; i < kBandTries; ++i) {
+        if (!chosen && cbs[i] <= kBandFill && zk - delta < zk) {
+          blo = zk - delta; bhi = (cfs[i] == 0) ? kInf : zk + delta; chosen = true;
         }
+        delta *= 0.5f;
       }
     }
     if (lane == 0) {
