@@ -1065,17 +1065,17 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
     const float zcn = zc[n];
     const int4* br = brect + (size_t)n * nrect;
     const float4* fr = frec + (size_t)n * F * 3;
-    // union boxes containing the pixel (ascending); 4 independent loads in flight per round
+    // union boxes containing the pixel (ascending); 8 independent loads in flight per round
     int nh = 0;
-    for (int r0 = 0; r0 < nrect; r0 += 256) {
-      int4 b[4];
+    for (int r0 = 0; r0 < nrect; r0 += 512) {
+      int4 b[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const int ri = r0 + u * 64 + lane;
         b[u] = (ri < nrect) ? br[ri] : make_int4(1, 0, 1, 0);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const bool hit = b[u].x <= pcol && pcol <= b[u].y && b[u].z <= prow && prow <= b[u].w;
         const unsigned long long bal = __ballot(hit);
         if (hit) { const int pos = nh + __popcll(bal & ((1ull << lane) - 1ull)); if (pos < kHitCap) hits[w][pos] = r0 + u * 64 + lane; }
@@ -1089,11 +1089,11 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
     const int2* fb = fbox + (size_t)n * F;
     int ncov = 0;
     if (nh <= kHitCap) {
-      for (int j = 0; j < nh; j += 4 * RPI) {
-        int ff[4];
-        int2 bx[4];
+      for (int j = 0; j < nh; j += 8 * RPI) {
+        int ff[8];
+        int2 bx[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
           const int hj = j + u * RPI + lane / kRectFaces;
           ff[u] = -1;
           bx[u] = make_int2(1, 1);
@@ -1103,7 +1103,7 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
           }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
           const bool cov = ff[u] >= 0 && box_contains(bx[u], pcol, prow);
           const unsigned long long bal = __ballot(cov);
           if (cov) { const int pos = ncov + __popcll(bal & ((1ull << lane) - 1ull)); if (pos < kCoverCap) fids[w][pos] = (unsigned short)ff[u]; }
@@ -1118,21 +1118,21 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
     // visit every candidate of the pixel in face order: fn(valid, pz, d, face) is called wave-wide
     auto scan_candidates = [&](auto&& fn) {
       if (compact) {
-        float4 pa, pb, pc;
-        bool plive;
-        auto prefetch = [&](int j) {
-          plive = (j + lane) < ncov;
-          if (plive) {
+        // records of two rounds (128 faces) in flight
+        float4 pa[2], pb[2], pc[2];
+        bool plive[2];
+        auto prefetch = [&](int j, int slot) {
+          plive[slot] = (j + lane) < ncov;
+          if (plive[slot]) {
             const int ff = fids[w][j + lane];
-            pa = fr[(size_t)ff * 3]; pb = fr[(size_t)ff * 3 + 1]; pc = fr[(size_t)ff * 3 + 2];
+            pa[slot] = fr[(size_t)ff * 3]; pb[slot] = fr[(size_t)ff * 3 + 1]; pc[slot] = fr[(size_t)ff * 3 + 2];
           }
         };
-        prefetch(0);
-        for (int j = 0; j < ncov; j += 64) {
-          const float4 a = pa, b = pb, c = pc;
-          const bool live = plive;
+        auto consume = [&](int j, int slot) {
+          const float4 a = pa[slot], b = pb[slot], c = pc[slot];
+          const bool live = plive[slot];
           const int cur_ff = live ? (int)fids[w][j + lane] : 0;
-          if (j + 64 < ncov) prefetch(j + 64);
+          if (j + 128 < ncov) prefetch(j + 128, slot);
           bool ok = false;
           PixEval e; e.pz = 0.f; e.d = 0.f;
           if (live) {
@@ -1141,6 +1141,12 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
             ok = face_pixel_eval(r, ppx, ppy, e);
           }
           fn(ok, e.pz - zcn, e.d, cur_ff);
+        };
+        prefetch(0, 0);
+        if (64 < ncov) prefetch(64, 1);
+        for (int j = 0; j < ncov; j += 128) {
+          consume(j, 0);
+          if (j + 64 < ncov) consume(j + 64, 1);
         }
       } else {                      // pathological: walk every face
         for (int f0 = 0; f0 < F; f0 += 64) {
