@@ -1461,10 +1461,14 @@ vertex_bwd_kernel(ModelDev m, int M, const float* __restrict__ proj, const float
       for (int a = 0; a < 3; ++a) g[a] += dverts_ext[((size_t)n * 3 + a) * Vp + v];
     }
     // translation adjoint: sum over vertices of the translated-vertex adjoint
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float s = block_sum(live ? g[a] : 0.f, red);
-      if (threadIdx.x == 0) dtr_part[((size_t)blockIdx.x * M + n) * 3 + a] = s;
+    {
+      const float s0 = wave_sum(live ? g[0] : 0.f), s1 = wave_sum(live ? g[1] : 0.f), s2 = wave_sum(live ? g[2] : 0.f);
+      __syncthreads();                               // red[] of the previous frame has been consumed
+      if ((threadIdx.x & 63) == 0) { float* q = &red[(threadIdx.x >> 6) * 4]; q[0] = s0; q[1] = s1; q[2] = s2; }
+      __syncthreads();
+      if (threadIdx.x < 3)
+        dtr_part[((size_t)blockIdx.x * M + n) * 3 + threadIdx.x] =
+            ((red[threadIdx.x] + red[4 + threadIdx.x]) + red[8 + threadIdx.x]) + red[12 + threadIdx.x];
     }
     // joints = J_regressor^T verts  (+ landmark picks)
     float dv[3] = {g[0], g[1], g[2]};
