@@ -9,14 +9,15 @@
 //   with 35 entries per row, the code path is the same and the sums run in the same joint order.
 //
 // Kernel -> reference map (file:line into /root/reference):
-//   shape_kernel        smal_torch.py:115 (+ :125-128 through the precomputed J0 + JS beta)
-//   pose_kernel         batch_lbs.py:33-52 (Rodrigues), :105-129 (limb scales), :131-168 (chain, A)
-//   skin_kernel         smal_torch.py:138-163 (pose blend, W*A, skinning) + renderer camera transform
+//   lbs_head_kernel     pose blocks: batch_lbs.py:33-52 (Rodrigues), :105-129 (limb scales), :131-168 (chain, A);
+//                       shape blocks: smal_torch.py:115 (+ :125-128 through the precomputed J0 + JS beta);
+//                       prior block: smal_fitter.py:162-171
+//   skin_mfma_kernel / skin_kernel   smal_torch.py:138-163 (pose blend, W*A, skinning) + renderer camera transform
 //   joints_kernel       smal_torch.py:171-184
 //   loss_kernel         smal_fitter.py:129-132,140-160,177-190 ; pose_prior_35.py:117-124
-//   shape_prior_kernel  smal_fitter.py:162-171
-//   face_bbox/bin/raster_fwd/raster_bwd   p3d_renderer.py:26-39,65-66 (pytorch3d rasterize + blend)
-//   vertex_bwd .. chain_bwd               autograd of the above (optimize_to_joints.py:136)
+//   face_bbox / raster_sweep / raster_resolve / raster_band / raster_select / raster_bwd
+//                       p3d_renderer.py:26-39,65-66 (pytorch3d rasterize_meshes + sigmoid_alpha_blend)
+//   vertex_bwd, lbs_bwd_mid, chain_bwd, assemble    autograd of the above (optimize_to_joints.py:136)
 //   adam_kernel         optimize_to_joints.py:96,137 (torch.optim.Adam, betas=(0.5,0.999))
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -86,98 +87,166 @@ __device__ __forceinline__ int frame_window_size(int n, int M, int window) {
 // ------------------------------------------------------------------------------------------------
 // K0: shape blend + rest joints
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-shape_kernel(ModelDev m, const float* __restrict__ betas, int betas_stride, int nb,
-             float* __restrict__ v_shaped /*[nbs][3][Vp]*/, float* __restrict__ Jrest /*[nbs][105]*/) {
-  const int s = blockIdx.y;
-  const float* beta = betas + (size_t)s * betas_stride;
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  const int Vp = m.Vp;
-  if (v < Vp) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      float acc = m.vt[a * Vp + v];
-      for (int b = 0; b < nb; ++b) acc = fmaf(beta[b], m.sd[((size_t)b * 3 + a) * Vp + v], acc);
-      v_shaped[((size_t)s * 3 + a) * Vp + v] = acc;
-    }
-  }
-  if (blockIdx.x == 0 && threadIdx.x < 105) {
-    float acc = m.Jt[threadIdx.x];
-    for (int b = 0; b < nb; ++b) acc = fmaf(m.JS[threadIdx.x * m.NBall + b], beta[b], acc);
-    Jrest[s * 105 + threadIdx.x] = acc;
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // K1: per-frame pose: Rodrigues, limb scales, kinematic chain, skinning transforms, pose feature
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
-pose_kernel(ModelDev m, int M, int Mp,
-            const float* __restrict__ theta /*[M][35][3] already masked*/,
-            const float* __restrict__ logscale, int ls_stride,
-            const float* __restrict__ Jrest, int j_stride,
-            float* __restrict__ Rm /*[M][35][9]*/, float* __restrict__ Gm /*[M][35][12]*/,
-            float* __restrict__ scm /*[M][35][3]*/, float* __restrict__ Am /*[M][35][12]*/,
-            float* __restrict__ pfT /*[308][Mp]*/) {
+// K0+K1a in one launch: per-frame pose blocks (masked axis-angles -> Rodrigues -> limb scales -> kinematic chain by
+// tree depth -> A_j and the pose feature; the rest joints J = Jt + JS beta are formed in place), the shape-blend
+// blocks (v_shaped = v_template + shapedirs beta) and, for the fitter, the shape-prior block.  The three parts are
+// independent and each is latency-bound: one launch instead of four.
+struct HeadArgs {
+  int M, Mp, nb, betas_stride, ls_stride, nshape_x, nshape, prior_D, prior_use_ls;
+  const float* betas;        // [nbs][betas_stride]
+  const float* theta_in;     // [M][105] ready-made (component API) or null
+  const float* grot;         // [M][3], jrot [M][102], masks: used when theta_in is null
+  const float* jrot;
+  const float* gmask;
+  const float* rmask;
+  const float* logscale;     // [.][6] or null
+  float* theta;              // [M][105] out (masked axis-angles)
+  float* Jrest;              // [nbs][105] out
+  float* v_shaped;           // [nbs][3][Vp] out
+  float *Rm, *Gm, *scm, *Am, *pfT;
+  const float* prior_prec;   // shape prior (null: none)
+  const float* prior_mean;
+  float prior_w;
+  float *prior_loss, *prior_gb, *prior_gls;
+};
+
+__device__ __forceinline__ void
+pose_block(const ModelDev& m, const HeadArgs& a, int n) {
+  __shared__ float th[105];
   __shared__ float R[35][9];
-  __shared__ float sc[35][3];
+  __shared__ float sc[35][3], isc[35][3];
   __shared__ float G[35][12];
   __shared__ float J[35][3];
-  __shared__ int par[35];
-  const int n = blockIdx.x, l = threadIdx.x;
-  if (l < 35) {
-    float th[3] = {theta[(n * 35 + l) * 3], theta[(n * 35 + l) * 3 + 1], theta[(n * 35 + l) * 3 + 2]};
-    float r[9];
-    rodrigues_fwd(th, r);
-#pragma unroll
-    for (int e = 0; e < 9; ++e) { R[l][e] = r[e]; Rm[(n * 35 + l) * 9 + e] = r[e]; }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const int idx = m.scale_idx[l * 3 + a];
-      const float sv = (logscale != nullptr && idx >= 0) ? expf(logscale[(size_t)n * ls_stride + idx]) : 1.0f;
-      sc[l][a] = sv;
-      scm[(n * 35 + l) * 3 + a] = sv;
-      J[l][a] = Jrest[(size_t)n * j_stride + l * 3 + a];
-    }
-    par[l] = m.parents[l];
+  __shared__ unsigned char t_lvl_off[36], t_lvl_joint[36], t_par[36];
+  const int l = threadIdx.x, M = a.M;
+  const TreeLevels& tl = m.tree;
+  if (l < 36) {
+    t_lvl_off[l] = tl.lvl_off[l];
+    if (l < 35) { t_lvl_joint[l] = tl.lvl_joint[l]; t_par[l] = (unsigned char)max(m.parents[l], 0); }
+  }
+  const int nlev = tl.nlev;
+  if (l < 105) {
+    float tv;
+    if (a.theta_in) tv = a.theta_in[(size_t)n * 105 + l];
+    else tv = (l < 3) ? a.grot[n * 3 + l] * a.gmask[l] : a.jrot[(size_t)n * 102 + (l - 3)] * a.rmask[l - 3];
+    th[l] = tv;
+    a.theta[(size_t)n * 105 + l] = tv;
+    // rest joint coordinate l of this frame's shape
+    const float* beta = a.betas + (size_t)(a.betas_stride ? n : 0) * a.betas_stride;
+    float acc = m.Jt[l];
+    for (int b = 0; b < a.nb; ++b) acc = fmaf(m.JS[l * m.NBall + b], beta[b], acc);
+    J[l / 3][l % 3] = acc;
+    if (a.betas_stride || n == 0) a.Jrest[(size_t)(a.betas_stride ? n : 0) * 105 + l] = acc;
+    const int idx = m.scale_idx[l];
+    const float sv = (a.logscale != nullptr && idx >= 0) ? expf(a.logscale[(size_t)n * a.ls_stride + idx]) : 1.0f;
+    sc[l / 3][l % 3] = sv; isc[l / 3][l % 3] = 1.0f / sv;
+    a.scm[(size_t)n * 105 + l] = sv;
   }
   __syncthreads();
-  for (int idx = l; idx < 306; idx += 64) {
+  if (l < 35) {
+    const float t3[3] = {th[l * 3], th[l * 3 + 1], th[l * 3 + 2]};
+    float r[9];
+    rodrigues_fwd(t3, r);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { R[l][e] = r[e]; a.Rm[((size_t)n * 35 + l) * 9 + e] = r[e]; }
+  }
+  __syncthreads();
+  for (int idx = l; idx < 306; idx += 256) {
     const int j = idx / 9 + 1, e = idx % 9;
-    pfT[(size_t)idx * Mp + n] = R[j][e] - ((e & 3) == 0 ? 1.0f : 0.0f);
+    a.pfT[(size_t)idx * a.Mp + n] = R[j][e] - ((e & 3) == 0 ? 1.0f : 0.0f);
   }
   if (l < 12) {
-    const int a = l >> 2, b = l & 3;
-    G[0][l] = (b < 3) ? R[0][a * 3 + b] : J[0][a];
+    const int r = l >> 2, c = l & 3;
+    G[0][l] = (c < 3) ? R[0][r * 3 + c] : J[0][r];
+  }
+  // the tree by depth: 12 lanes per joint of the level, first wave only (its LDS operations complete in order)
+  if (l < 64) {
+    const int slot = l / 12, e = l % 12;
+    for (int L = 1; L < nlev; ++L) {
+      const int j0 = t_lvl_off[L], nj = t_lvl_off[L + 1] - j0;
+      for (int base = 0; base < nj; base += 5) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (slot < 5 && base + slot < nj) {
+          const int i = t_lvl_joint[j0 + base + slot], p = t_par[i];
+          const int r = e >> 2, c = e & 3;
+          float acc;
+          if (c < 3) {
+            acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc = fmaf(G[p][r * 4 + q], R[i][q * 3 + c] * sc[i][c] * isc[p][q], acc);
+          } else {
+            acc = G[p][r * 4 + 3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc = fmaf(G[p][r * 4 + q], J[i][q] - J[p][q], acc);
+          }
+          G[i][e] = acc;
+        }
+      }
+    }
   }
   __syncthreads();
-  for (int i = 1; i < 35; ++i) {
-    const int p = par[i];
-    if (l < 12) {
-      const int a = l >> 2, b = l & 3;
-      float acc;
-      if (b < 3) {
-        acc = 0.f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) acc = fmaf(G[p][a * 4 + c], R[i][c * 3 + b] * sc[i][b] / sc[p][c], acc);
-      } else {
-        acc = G[p][a * 4 + 3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) acc = fmaf(G[p][a * 4 + c], J[i][c] - J[p][c], acc);
-      }
-      G[i][l] = acc;
-    }
-    __syncthreads();
-  }
-  for (int idx = l; idx < 35 * 12; idx += 64) {
-    const int j = idx / 12, e = idx % 12, a = e >> 2, b = e & 3;
+  for (int idx = l; idx < 35 * 12; idx += 256) {
+    const int j = idx / 12, e = idx % 12, r = e >> 2, c = e & 3;
     float val = G[j][e];
-    if (b == 3) {
+    if (c == 3) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) val = fmaf(-G[j][a * 4 + c], J[j][c], val);
+      for (int q = 0; q < 3; ++q) val = fmaf(-G[j][r * 4 + q], J[j][q], val);
     }
-    Am[(size_t)n * 420 + idx] = val;
-    Gm[(size_t)n * 420 + idx] = G[j][e];
+    a.Am[(size_t)n * 420 + idx] = val;
+    a.Gm[(size_t)n * 420 + idx] = G[j][e];
+  }
+  (void)M;
+}
+
+__global__ void __launch_bounds__(256)
+lbs_head_kernel(ModelDev m, HeadArgs a) {
+  int blk = blockIdx.x;
+  if (blk < a.M) { pose_block(m, a, blk); return; }
+  blk -= a.M;
+  if (blk < a.nshape) {
+    const int s = blk / a.nshape_x;
+    const float* beta = a.betas + (size_t)s * a.betas_stride;
+    const int v = (blk % a.nshape_x) * 256 + threadIdx.x;
+    const int Vp = m.Vp;
+    if (v < Vp) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float acc = m.vt[c * Vp + v];
+        for (int b = 0; b < a.nb; ++b) acc = fmaf(beta[b], m.sd[((size_t)b * 3 + c) * Vp + v], acc);
+        a.v_shaped[((size_t)s * 3 + c) * Vp + v] = acc;
+      }
+    }
+    return;
+  }
+  // shape prior: w_eff * mean_c( ((x - mean) prec)_c ^2 ), x = [betas | log scales]
+  if (a.prior_prec && threadIdx.x < 64) {
+    __shared__ float x[32], res[32];
+    const int t = threadIdx.x, D = a.prior_D;
+    if (t < D) x[t] = ((t < 20) ? a.betas[t] : a.logscale[t - 20]) - a.prior_mean[t];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    float lv = 0.f;
+    if (t < D) {
+      float acc = 0.f;
+      for (int r = 0; r < D; ++r) acc = fmaf(x[r], a.prior_prec[r * D + t], acc);
+      res[t] = acc;
+      lv = acc * acc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    lv = wave_sum(lv);
+    if (t == 0) *a.prior_loss = a.prior_w * lv / (float)D;
+    if (t < D) {
+      float acc = 0.f;
+      for (int c = 0; c < D; ++c) acc = fmaf(res[c], a.prior_prec[t * D + c], acc);
+      acc *= 2.0f * a.prior_w / (float)D;
+      if (t < 20) a.prior_gb[t] = acc; else if (a.prior_use_ls) a.prior_gls[t - 20] = acc;
+    }
   }
 }
 
@@ -551,7 +620,7 @@ loss_kernel(LossArgs a) {
     o[0] = a.w_j2d * nj * l_joint;
     o[1] = a.w_pose * np_ * l_pose;
     o[2] = a.w_splay * l_splay;
-    o[3] = 0.f;                // betas (shape_prior_kernel)
+    o[3] = 0.f;                // betas (prior block of lbs_head_kernel)
     o[4] = 0.f;                // silhouette (tile partials)
     o[5] = l_tj; o[6] = l_tg; o[7] = l_tt;
   }
@@ -559,32 +628,6 @@ loss_kernel(LossArgs a) {
 
 // shape prior (smal_fitter.py:162-171): loss = w * mean(((b|ls) - mu) P)^2 counted once per window.
 // single block; betas/logscale shared across frames (fitter) -> grads are for the shared vectors.
-__global__ void __launch_bounds__(64)
-shape_prior_kernel(const float* __restrict__ betas, const float* __restrict__ logscale, int use_ls,
-                   const float* __restrict__ prec, const float* __restrict__ mean, int D,
-                   float w_eff /* w_betas * num_windows */, float* __restrict__ loss_out,
-                   float* __restrict__ gb /*[20]*/, float* __restrict__ gls /*[6]*/) {
-  __shared__ float x[32], res[32];
-  const int t = threadIdx.x;
-  if (t < D) x[t] = ((t < 20) ? betas[t] : logscale[t - 20]) - mean[t];
-  __syncthreads();
-  float l = 0.f;
-  if (t < D) {
-    float acc = 0.f;
-    for (int r = 0; r < D; ++r) acc = fmaf(x[r], prec[r * D + t], acc);
-    res[t] = acc;
-    l = acc * acc;
-  }
-  __syncthreads();
-  l = wave_sum(l);
-  if (t == 0) *loss_out = w_eff * l / (float)D;
-  if (t < D) {
-    float acc = 0.f;
-    for (int c = 0; c < D; ++c) acc = fmaf(res[c], prec[t * D + c], acc);
-    acc *= 2.0f * w_eff / (float)D;
-    if (t < 20) gb[t] = acc; else if (use_ls) gls[t - 20] = acc;
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // K5: soft-silhouette rasteriser
@@ -2002,11 +2045,28 @@ assemble_kernel(AssembleArgs a) {
   __syncthreads();
   if (!is_last) return;
   __threadfence();
+  // silhouette: the kAsmLoss partials, one per lane, added in a fixed butterfly order
+  static_assert(kAsmLoss == 16, "butterfly below");
+  float lsil = 0.f;
+  if (t < 64) {
+    const volatile float* lp = a.lpart;
+    lsil = (t < kAsmLoss) ? lp[t] : 0.f;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) lsil += __shfl_xor(lsil, o, 64);
+  }
+  // per-frame terms: 32 frame slices x 8 terms in parallel, then the slices in order
+  {
+    const int k = t & 7, sl = t >> 3;
+    float acc = 0.f;
+    if (a.loss_part) for (int n = sl; n < M; n += 32) acc += a.loss_part[n * 8 + k];
+    part[sl][k] = acc;
+  }
+  __syncthreads();
   if (t < 8) {
     float acc = 0.f;
     if (t == 3) acc = a.loss_betas ? *a.loss_betas : 0.f;
-    else if (t == 4) { const volatile float* lp = a.lpart; for (int i = 0; i < kAsmLoss; ++i) acc += lp[i]; }
-    else if (a.loss_part) for (int n = 0; n < M; ++n) acc += a.loss_part[n * 8 + t];
+    else if (t == 4) acc = lsil;
+    else for (int i = 0; i < 32; ++i) acc += part[i][t];
     a.losses[t] = acc;
   }
   if (t == 0) *a.counter = 0;
