@@ -1,0 +1,143 @@
+"""GPU tests at BASELINE.json's sizes and edge cases the reference's configurations imply (-m gpu).
+
+The oracle is too slow for 64 frames x 256^2 x many iterations, so the full-size checks use size-independent
+properties: bit-reproducibility, independence of the rasteriser's cached depth bounds, and the analytic gradient
+against a directional finite difference of the loss.  Single cases at 512^2, at an image size that is not a
+multiple of the 16-pixel tiles, off-screen meshes and the single-image configuration are checked against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from . import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+
+
+def _fullsize(scene="survey"):
+    import bench
+    from smalify_amd import engine as eng, fitter as fit, synthetic
+    _, _, dm = pc.get_model()
+    e = eng.Engine(dm, bench.NUM_FRAMES, bench.IMAGE_SIZE)
+    e.set_pose_prior(*synthetic.synthetic_pose_prior())
+    gt, tj, vis, tsil, sp = bench.build_problem(e, torch, scene)
+    e.set_shape_prior(*sp)
+
+    def new_fitter(engine=e):
+        return fit.FusedFitter(engine, tj, vis, tsil, bench.WINDOW, True, sp[1][:20], sp[1][20:26])
+    return e, new_fitter, dm, sp
+
+
+def _run(fitter, iters, stage=2):
+    from smalify_amd import config as cfg
+    W = np.array(cfg.OPT_WEIGHTS).T
+    fitter.begin_stage(stage)
+    for _ in range(iters):
+        fitter.step(W[stage][:6], float(W[stage][6]), float(W[stage][8]), stage)
+    return W
+
+
+def test_fullsize_fit_is_bit_reproducible():
+    """64 frames, 256^2: two independent runs of stage 0 + stage 1 iterations end in identical bits (all reductions
+    are order-fixed: integer atomics, butterfly shuffles, last-block tails)."""
+    e, new_fitter, _, _ = _fullsize()
+    outs = []
+    for _ in range(2):
+        e.reset_raster_cache()
+        f = new_fitter()
+        _run(f, 8, stage=0)
+        _run(f, 12, stage=1)
+        outs.append((f.flat.clone(), f.losses.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert e.status() == 0
+
+
+def test_fullsize_cached_bounds_do_not_change_the_fit():
+    """Same 10 stage-1 iterations (large steps: the cache misses a lot) with the depth-bound cache kept and with the
+    cache forgotten before every evaluation: parameters agree to accumulated float32 noise."""
+    e, new_fitter, _, _ = _fullsize()
+    from smalify_amd import config as cfg
+    W = np.array(cfg.OPT_WEIGHTS).T
+    res = []
+    for reset in (False, True):
+        e.reset_raster_cache()
+        f = new_fitter()
+        _run(f, 6, stage=0)
+        f.begin_stage(1)
+        for _ in range(10):
+            if reset:
+                e.reset_raster_cache()
+            f.step(W[1][:6], float(W[1][6]), float(W[1][8]), 1)
+        res.append(f.flat.clone())
+    rel = float((res[0] - res[1]).norm() / res[1].norm())
+    assert rel < 2e-5, rel
+
+
+def test_fullsize_gradient_matches_directional_difference():
+    """d loss / d parameters along the gradient direction vs a central difference of the float32 loss (64 frames, 256^2)."""
+    e, new_fitter, _, _ = _fullsize()
+    from smalify_amd import config as cfg
+    W = np.array(cfg.OPT_WEIGHTS).T
+    f = new_fitter()
+    _run(f, 6, stage=0)
+    _run(f, 6, stage=1)
+    stage = 2
+    names = f.trainable(stage)
+    f.evaluate(W[stage][:6], float(W[stage][6]), stage)
+    g = f.grad.clone()
+    p0 = f.flat.clone()
+    # along the (normalised) gradient itself: the largest signal over the float32 rounding of the loss, and a step
+    # sized for a loss change of ~0.5 (total loss ~1e2, float32 resolution ~1e-5 relative)
+    gn = float(g.double().norm())
+    d = g / gn
+    eps = 0.25 / gn
+    tot = []
+    for sgn in (+1.0, -1.0):
+        f.flat.copy_(p0 + sgn * eps * d)
+        f.evaluate(W[stage][:6], float(W[stage][6]), stage)
+        tot.append(float(f.losses.double().sum()))
+    f.flat.copy_(p0)
+    fd = (tot[0] - tot[1]) / (2 * eps)
+    an = float((g.double() * d.double()).sum())
+    assert abs(fd - an) <= 0.05 * max(abs(an), abs(fd)), (fd, an, eps)
+
+
+@pytest.mark.parametrize("M,S,z,seed", [(1, 512, 1.45, 23), (2, 100, 1.4, 29)])
+def test_renderer_other_sizes(M, S, z, seed):
+    """512^2 (BASELINE config 5) and an image size that is not a multiple of the 16-pixel resolve tiles"""
+    m = pc.case_render(M, S, z, seed)
+    assert m["render_status"] == 0
+    assert m["sil_maxabs"] < 2e-3, m
+    assert m["sil_frac_gt_1e-4"] < 5e-3, m
+    assert m["render_proj_maxabs_px"] < 2e-3, m
+    assert m["render_dverts_rel"] < 1e-2, m
+
+
+def test_renderer_mesh_off_screen():
+    """no face box on screen: empty active region, silhouette exactly 0, zero vertex gradient"""
+    md, om, _ = pc.get_model()
+    e, _, _ = pc.get_engine(8, 64)
+    p = pc.random_pose(2, 31)
+    from oracle import smal_oracle as so
+    theta = np.concatenate([p["global_rotation"][:, None], p["joint_rotations"]], 1)
+    with torch.no_grad():
+        vo, jo, _, _ = so.smal_forward(om, torch.from_numpy(np.tile(p["betas"], (2, 1))).double(),
+                                       torch.from_numpy(theta).double(),
+                                       torch.from_numpy(np.tile(p["log_beta_scales"], (2, 1))).double())
+    verts = (vo + torch.tensor([40.0, 0.0, 0.0]).double()).float().cuda().contiguous()
+    pts = jo[:, so.CANONICAL].float().cuda().contiguous()
+    sil, _ = e.render_forward(verts, pts)
+    assert float(sil.abs().max()) == 0.0
+    dv = e.render_backward(verts, sil, torch.ones_like(sil))
+    assert float(dv.abs().max()) == 0.0
+    assert e.status() == 0
+
+
+def test_fit_single_image_configuration():
+    """BASELINE config 1: one frame, window 1 (temporal terms vanish), stage 2 weights"""
+    m = pc.case_fit(1, 128, 1, 2)
+    assert m["fit_status"] == 0
+    assert m["fit_total_rel"] < 1e-4, m
+    for k, v in m.items():
+        if k.startswith("fit_grad_") and k.endswith("_rel"):
+            assert v < 2e-3, (k, v, m)
