@@ -89,7 +89,7 @@ struct AssembleArgs {
   const float* loss_part;
   const float* loss_betas;
   const float* tile_loss;
-  const float* qloss;      // weighted silhouette loss of the queued (K-truncated) pixels, one partial per select block
+  const long long* qloss;  // weighted silhouette loss of the queued pixels, one 2^-44 fixed-point partial per band / select block
   int nqblk;
   float* lpart;            // [kAsmLoss] partial sums of the silhouette loss (assemble_kernel)
   int* counter;            // arrival counter of assemble_kernel's blocks (zero between launches)

@@ -858,6 +858,7 @@ raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, const float* 
     const int2 box = boxes[k];
     const int c0 = box.x & 0xffff, c1 = box.x >> 16, r0 = box.y & 0xffff, r1 = box.y >> 16;
     if (c0 > c1) continue;
+    const FaceRec rk = recs[k];                      // in registers: the LDS atomics below would force a reload per pixel
     // the box's pixels in row-major order, 16 at a time (no lane idles except in the last round)
     const int bw = c1 - c0 + 1, npx = bw * (r1 - r0 + 1);
     const float inv_bw = 1.0f / (float)bw;
@@ -868,10 +869,10 @@ raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, const float* 
         const int row = r0 + ry, col = c0 + cx;
         const float2 zb = zbp[row * S + col];
         const float ppx = pix_to_ndc(col, inv_s), ppy = pix_to_ndc(row, inv_s);
-        const float rz = face_pixel_depth(recs[k], ppx, ppy) - zcn;   // depth relative to the frame reference
+        const float rz = face_pixel_depth(rk, ppx, ppy) - zcn;   // depth relative to the frame reference
         if (!(rz <= zb.y)) continue;                   // beyond the pixel's far bound: dropped whatever its distance
         PixEval e;
-        if (!face_pixel_eval(recs[k], ppx, ppy, e)) continue;
+        if (!face_pixel_eval(rk, ppx, ppy, e)) continue;
         if (rz <= zb.x) {
           const int lxw = col - wx0, lyw = row - wy0;
           if (lxw < kAccWin && lyw < kAccWin) atomicAdd(&acc[lyw * kAccWin + lxw], pack_candidate(e.d));
@@ -899,6 +900,19 @@ raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, const float* 
     const unsigned long long v = acc[lyw * kAccWin + lxw];
     if (v) atomicAdd(&ga[(wy0 + lyw) * S + wx0 + lxw], v);
   }
+}
+
+// The queues of the band / select kernels are filled in a non-deterministic order, so which block sums which pixel
+// varies from run to run: their loss partials are kept as 2^-44 fixed-point integers (integer adds commute), which
+// makes the reported loss bit-reproducible like everything else.
+constexpr float kLossFix = 17592186044416.0f;   // 2^44
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int lo = __shfl_xor((int)(v & 0xffffffffll), o, 64), hi = __shfl_xor((int)(v >> 32), o, 64);
+    v += ((long long)hi << 32) | (unsigned int)lo;
+  }
+  return v;
 }
 
 // 5c: resolve.  With c = #candidates <= lo and b = #band entries of a pixel, the K nearest are known exactly when
@@ -993,7 +1007,7 @@ raster_band_kernel(int S, int M, int window, float w_sil, unsigned long long* __
                    unsigned* __restrict__ bcnt, const float2* __restrict__ blist,
                    const float* __restrict__ tsil, float* __restrict__ sil_out, float2* __restrict__ gz,
                    int* __restrict__ qcount, int* __restrict__ queue, const int* __restrict__ bqueue,
-                   float* __restrict__ bloss /*[gridDim.x]: weighted |sil - target| per block, or null*/) {
+                   long long* __restrict__ bloss /*[gridDim.x]: weighted |sil - target| per block in 2^-44 fixed point, or null*/) {
   static_assert(kBandCap == 32, "one band entry per lane of a half-wave");
   __shared__ __attribute__((aligned(16))) float zs[8][32];
   __shared__ float red[16];
@@ -1003,7 +1017,7 @@ raster_band_kernel(int S, int M, int window, float w_sil, unsigned long long* __
   const int t = threadIdx.x, hw = t >> 5, hl = t & 31;
   const int nb = qcount[1];
   const int npix = S * S;
-  float lacc = 0.f;
+  long long lacc = 0;
   for (int j = blockIdx.x * 8 + hw; j < nb; j += gridDim.x * 8) {
     const int gp = bqueue[j];
     const size_t pi = (size_t)gp;
@@ -1046,7 +1060,7 @@ raster_band_kernel(int S, int M, int window, float w_sil, unsigned long long* __
           const int n = gp / npix;
           const float wn = w_sil / ((float)frame_window_size(n, M, window) * (float)S * (float)S);
           const float diff = sil - ts;
-          lacc += fabsf(diff) * wn;
+          lacc += (long long)(fabsf(diff) * wn * kLossFix);
           const float sgn = (diff > 0.f) ? 1.0f : ((diff < 0.f) ? -1.0f : 0.0f);
           gx = -wn * sgn * alpha * (1.0f / kSigma);
         }
@@ -1058,8 +1072,11 @@ raster_band_kernel(int S, int M, int window, float w_sil, unsigned long long* __
     __builtin_amdgcn_wave_barrier();
   }
   if (bloss) {
-    lacc = block_sum(lacc, red);
-    if (t == 0) bloss[blockIdx.x] = lacc;
+    __shared__ long long lred[4];
+    const long long ws = wave_sum_i64(lacc);
+    if ((t & 63) == 0) lred[t >> 6] = ws;
+    __syncthreads();
+    if (t == 0) bloss[blockIdx.x] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
   }
 }
 
@@ -1078,15 +1095,15 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
                      const int4* __restrict__ brect, const int2* __restrict__ fbox, const int* __restrict__ qcount,
                      const int* __restrict__ queue, const float* __restrict__ tsil,
                      float* __restrict__ sil_out, float2* __restrict__ gz, float2* __restrict__ zband,
-                     float* __restrict__ qloss /*[gridDim.x]: weighted |sil - target| summed per block, or null*/, int dbg) {
+                     long long* __restrict__ qloss /*[gridDim.x]: weighted |sil - target| per block in 2^-44 fixed point, or null*/, int dbg) {
   __shared__ unsigned hist[kSelWaves][256];
   __shared__ float2 cand[kSelWaves][kCandCap];
   __shared__ unsigned short fids[kSelWaves][kCoverCap];
   // the union-box hit list is consumed (stage A) before the first candidate is written (stage B): share storage
   int (*hits)[2 * kCandCap] = reinterpret_cast<int (*)[2 * kCandCap]>(&cand[0][0]);
   static_assert(kHitCap <= 2 * kCandCap, "hit list must fit in the candidate buffer");
-  __shared__ float wloss[kSelWaves];
-  float lacc = 0.f;
+  __shared__ long long wloss[kSelWaves];
+  long long lacc = 0;
   constexpr int K = kFacesPerPixel;
   constexpr int RC = kCandCap / 64;
   constexpr int RPI = 64 / kRectFaces;      // union boxes handled per wave iteration
@@ -1380,14 +1397,14 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
       }
       gz[pi] = make_float2(gx, zmid);
       zband[pi] = make_float2(blo, bhi);
-      lacc += l;
+      lacc += (long long)(l * kLossFix);
     }
     __builtin_amdgcn_wave_barrier();
   }
   if (qloss) {
     if (lane == 0) wloss[w] = lacc;
     __syncthreads();
-    if (t == 0) { float tot = 0.f; for (int i = 0; i < kSelWaves; ++i) tot += wloss[i]; qloss[blockIdx.x] = tot; }
+    if (t == 0) { long long tot = 0; for (int i = 0; i < kSelWaves; ++i) tot += wloss[i]; qloss[blockIdx.x] = tot; }
   }
 }
 
@@ -2033,7 +2050,11 @@ assemble_kernel(AssembleArgs a) {
         lsil += a.tile_loss[k] * (a.w_sil / ((float)Bn * (float)a.S * (float)a.S));
       }
     }
-    if (a.qloss) for (int k = role * 256 + t; k < a.nqblk; k += kAsmLoss * 256) lsil += a.qloss[k];
+    if (a.qloss) {
+      long long qs = 0;
+      for (int k = role * 256 + t; k < a.nqblk; k += kAsmLoss * 256) qs += a.qloss[k];
+      lsil += (float)((double)qs * (1.0 / (double)kLossFix));
+    }
     lsil = block_sum(lsil, red);
     if (t == 0) a.lpart[role] = lsil;
   }

@@ -168,30 +168,33 @@ struct PixEval {
   bool inside;
 };
 
-// true when the face contributes to pixel centre (px, py) (pytorch3d naive rasteriser inclusion test)
+// true when the face contributes to pixel centre (px, py) (pytorch3d naive rasteriser inclusion test).
+// Every multiply-add is an explicit fmaf and no other a*b+c pattern is left for the compiler to contract: the
+// two-pixel packed form in the kernels (face_pixel_eval2) performs the same IEEE operations in the same order, so the
+// two agree bitwise (the K-nearest bookkeeping relies on every kernel seeing the same candidate set and depths).
 SMALFIT_HD bool face_pixel_eval(const FaceRec& r, float px, float py, PixEval& o) {
   const float dx = px - r.ax, dy = py - r.ay;
-  const float c1 = dx * r.e1y - dy * r.e1x;          // E(p; a, b)
-  const float c2 = dx * r.e2y - dy * r.e2x;          // -E(p; c, a)
+  const float c1 = fmaf(dx, r.e1y, -(dy * r.e1x));   // E(p; a, b)
+  const float c2 = fmaf(dx, r.e2y, -(dy * r.e2x));   // -E(p; c, a)
   const float w2 = c1 * r.inv_den;
   const float w1 = -c2 * r.inv_den;
-  const float w0 = (c2 - c1 + r.area) * r.inv_den;   // E(p; b, c) / (area + eps)
+  const float w0 = ((c2 - c1) + r.area) * r.inv_den; // E(p; b, c) / (area + eps)
   o.inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
   const float pz = face_depth(r, dx, dy);
   o.pz = pz;
   // edge a-b
-  float t1 = fminf(fmaxf((dx * r.e1x + dy * r.e1y) * r.il1 + r.t01, 0.0f), 1.0f);
-  const float q1x = dx - t1 * r.e1x, q1y = dy - t1 * r.e1y;
-  const float d1 = q1x * q1x + q1y * q1y;
+  const float t1 = fminf(fmaxf(fmaf(fmaf(dy, r.e1y, dx * r.e1x), r.il1, r.t01), 0.0f), 1.0f);
+  const float q1x = fmaf(-t1, r.e1x, dx), q1y = fmaf(-t1, r.e1y, dy);
+  const float d1 = fmaf(q1y, q1y, q1x * q1x);
   // edge a-c
-  float t2 = fminf(fmaxf((dx * r.e2x + dy * r.e2y) * r.il2 + r.t02, 0.0f), 1.0f);
-  const float q2x = dx - t2 * r.e2x, q2y = dy - t2 * r.e2y;
-  const float d2 = q2x * q2x + q2y * q2y;
+  const float t2 = fminf(fmaxf(fmaf(fmaf(dy, r.e2y, dx * r.e2x), r.il2, r.t02), 0.0f), 1.0f);
+  const float q2x = fmaf(-t2, r.e2x, dx), q2y = fmaf(-t2, r.e2y, dy);
+  const float d2 = fmaf(q2y, q2y, q2x * q2x);
   // edge b-c
   const float ex = dx - r.e1x, ey = dy - r.e1y;
-  float t3 = fminf(fmaxf((ex * r.e3x + ey * r.e3y) * r.il3 + r.t03, 0.0f), 1.0f);
-  const float q3x = ex - t3 * r.e3x, q3y = ey - t3 * r.e3y;
-  const float d3 = q3x * q3x + q3y * q3y;
+  const float t3 = fminf(fmaxf(fmaf(fmaf(ey, r.e3y, ex * r.e3x), r.il3, r.t03), 0.0f), 1.0f);
+  const float q3x = fmaf(-t3, r.e3x, ex), q3y = fmaf(-t3, r.e3y, ey);
+  const float d3 = fmaf(q3y, q3y, q3x * q3x);
   float dist = d1; o.qx = q1x; o.qy = q1y; o.tc = t1; o.edge = 0;
   if (d2 < dist) { dist = d2; o.qx = q2x; o.qy = q2y; o.tc = t2; o.edge = 1; }
   if (d3 < dist) { dist = d3; o.qx = q3x; o.qy = q3y; o.tc = t3; o.edge = 2; }
