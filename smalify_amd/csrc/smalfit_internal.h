@@ -92,6 +92,7 @@ struct AssembleArgs {
   const long long* qloss;  // weighted silhouette loss of the queued pixels, one 2^-44 fixed-point partial per band / select block
   int nqblk;
   float* lpart;            // [kAsmLoss] partial sums of the silhouette loss (assemble_kernel)
+  long long* qpart;        // [kAsmLoss] integer partial sums of the queue kernels' loss
   int* counter;            // arrival counter of assemble_kernel's blocks (zero between launches)
   float* g_betas;
   float* g_ls;

@@ -860,13 +860,15 @@ raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, const float* 
     if (c0 > c1) continue;
     const FaceRec rk = recs[k];                      // in registers: the LDS atomics below would force a reload per pixel
     // the box's pixels in row-major order, 16 at a time (no lane idles except in the last round)
+    // (row, col) advance by 16 pixels per round: 16 = srow * bw + scol, one conditional wrap
     const int bw = c1 - c0 + 1, npx = bw * (r1 - r0 + 1);
-    const float inv_bw = 1.0f / (float)bw;
+    const int srow = 16 / bw, scol = 16 - srow * bw;
+    int ry = sub / bw, cx = sub - ry * bw;
     for (int q = sub; q < npx; q += 16) {
       {
-        int ry = (int)(((float)q + 0.5f) * inv_bw), cx = q - ry * bw;
-        if (cx < 0) { --ry; cx += bw; } else if (cx >= bw) { ++ry; cx -= bw; }
         const int row = r0 + ry, col = c0 + cx;
+        cx += scol; ry += srow;
+        if (cx >= bw) { cx -= bw; ++ry; }
         const float2 zb = zbp[row * S + col];
         const float ppx = pix_to_ndc(col, inv_s), ppy = pix_to_ndc(row, inv_s);
         const float rz = face_pixel_depth(rk, ppx, ppy) - zcn;   // depth relative to the frame reference
@@ -1434,12 +1436,13 @@ raster_bwd_kernel(int F, int S, const float4* __restrict__ frec, const float* __
       const float zcn = zc[n];
       const float2* gp = gz + (size_t)n * S * S;
       const int bw = c1 - c0 + 1, npx = bw * (r1 - r0 + 1);
-      const float inv_bw = 1.0f / (float)bw;
+      const int srow = 16 / bw, scol = 16 - srow * bw;
+      int ry = sub / bw, cx = sub - ry * bw;
       for (int q = sub; q < npx; q += 16) {
         {
-          int ry = (int)(((float)q + 0.5f) * inv_bw), cx = q - ry * bw;
-          if (cx < 0) { --ry; cx += bw; } else if (cx >= bw) { ++ry; cx -= bw; }
           const int row = r0 + ry, col = c0 + cx;
+          cx += scol; ry += srow;
+          if (cx >= bw) { cx -= bw; ++ry; }
           const float2 g = gp[row * S + col];
           if (g.x == 0.f) continue;
           PixEval e;
@@ -2050,13 +2053,15 @@ assemble_kernel(AssembleArgs a) {
         lsil += a.tile_loss[k] * (a.w_sil / ((float)Bn * (float)a.S * (float)a.S));
       }
     }
-    if (a.qloss) {
-      long long qs = 0;
-      for (int k = role * 256 + t; k < a.nqblk; k += kAsmLoss * 256) qs += a.qloss[k];
-      lsil += (float)((double)qs * (1.0 / (double)kLossFix));
-    }
-    lsil = block_sum(lsil, red);
-    if (t == 0) a.lpart[role] = lsil;
+    // the queue kernels' partials are integers whose split over blocks varies from run to run: add them up as
+    // integers (exact, order-free) and convert the grand total once, in the last block
+    long long qs = 0;
+    if (a.qloss) for (int k = role * 256 + t; k < a.nqblk; k += kAsmLoss * 256) qs += a.qloss[k];
+    qs = wave_sum_i64(qs);
+    __shared__ long long qred[4];
+    if ((t & 63) == 0) qred[t >> 6] = qs;
+    lsil = block_sum(lsil, red);                        // (contains the barriers that also cover qred)
+    if (t == 0) { a.lpart[role] = lsil; a.qpart[role] = (qred[0] + qred[1]) + (qred[2] + qred[3]); }
   }
   if (!a.losses) return;
   // ---- the last block to arrive finishes the loss terms: [joint, pose, splay, betas, sil, temp_joint, temp_global, temp_trans]
@@ -2074,6 +2079,10 @@ assemble_kernel(AssembleArgs a) {
     lsil = (t < kAsmLoss) ? lp[t] : 0.f;
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) lsil += __shfl_xor(lsil, o, 64);
+    const volatile long long* qp = a.qpart;
+    long long qtot = (t < kAsmLoss) ? qp[t] : 0ll;
+    qtot = wave_sum_i64(qtot);
+    lsil += (float)((double)qtot * (1.0 / (double)kLossFix));
   }
   // per-frame terms: 32 frame slices x 8 terms in parallel, then the slices in order
   {
