@@ -665,12 +665,18 @@ constexpr int kAccWin = SMALFIT_ACC_WIN;  // LDS accumulator window edge (pixels
 constexpr int kCountShift = 50;
 constexpr float kLogFix = 16777216.0f;    // 2^24
 constexpr int kBandCap = 32;              // per-pixel list of candidates between the two cached depth bounds
-constexpr int kBandFill = 24;             // the select kernel sizes the band to hold at most this many entries
+#ifndef SMALFIT_BAND_FILL
+#define SMALFIT_BAND_FILL 30
+#endif
+constexpr int kBandFill = SMALFIT_BAND_FILL;   // the select kernel sizes the band to hold at most this many entries
 #ifndef SMALFIT_BAND_STAGE
 #define SMALFIT_BAND_STAGE 128
 #endif
 constexpr int kBandStage = SMALFIT_BAND_STAGE;   // band entries staged per wave in the sweep before a batched append
-constexpr float kBandHalf = 8.0f;         // initial half-width of the band, in mean depth gaps of the K nearest
+#ifndef SMALFIT_BAND_HALF
+#define SMALFIT_BAND_HALF 8.0f
+#endif
+constexpr float kBandHalf = SMALFIT_BAND_HALF;   // initial half-width of the band, in mean depth gaps of the K nearest
 
 __device__ __forceinline__ unsigned orderable(float f) {
   const unsigned u = __float_as_uint(f);
@@ -1691,7 +1697,10 @@ dbeta_block(const ModelDev& m, int M, int nb, int shared, int bx, int by, int bz
 // a lane fetches FOUR consecutive columns (one 16-byte load; 16 rows x 64 bytes per instruction) and the four
 // v_mfma_f32_16x16x4_f32 that follow pair component i of A with component i of B: the instruction only needs A and B
 // to agree on which column sits in which k slot.
-constexpr int PBM_SPLITS = 6, PBM_U = 4;
+#ifndef SMALFIT_PBM_SPLITS
+#define SMALFIT_PBM_SPLITS 6
+#endif
+constexpr int PBM_SPLITS = SMALFIT_PBM_SPLITS, PBM_U = 4;
 __device__ __forceinline__ void
 poseblend_bwd_mfma_block(const ModelDev& m, int M, int ftile, int kpair, int split, const float* __restrict__ dvp,
                          float* __restrict__ dpf_part /*[PBM_SPLITS][M][308]*/, float (*red)[8][64]) {

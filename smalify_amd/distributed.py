@@ -5,16 +5,18 @@ The reference has no multi-GPU path; what shards here is its p
 every loss term of smal_fitter.py:107-175 is a sum over frames given the shared shape parameters, and
 the temporal term (smal_fitter.py:177-190) couples only adjacent frames.  Per iteration each rank
 
-  1. all-gathers a 2x108-float record (masked pose + translation of its first and last frame) so that
-     the temporal pairs that straddle a shard boundary see their neighbour (the pair (i, i+1) is owned,
-     for the loss value, by the rank that owns frame i),
-  2. evaluates its own frames (HIP engine),
-  3. all-reduces (sum) the 26-float gradient of the shared betas / limb scales,
-  4. applies Adam locally; the shared parameters evolve identically on every rank because they see the
-     same reduced gradient from the same state.
+  1. evaluates its own frames (HIP engine) with the neighbours' boundary frames (halo) it already holds,
+  2. applies Adam to its per-frame parameters (their gradients are local),
+  3. all-gathers ONE small record: its partial gradient of the shared betas / limb scales (26 floats) and the
+     masked pose + translation of its first and last frame *after* step 2 (2 x 108 floats) -- the halo of the
+     next iteration,
+  4. adds the partial shape gradients in rank order (identical on every rank, deterministic) and applies Adam
+     to the shared parameters, which therefore evolve identically everywhere.
 
-Messages are a few hundred bytes, i.e. pure latency on xGMI; there is no bulk exchange to overlap.
-Shards must start on window boundaries so that the per-window normalisers match the unsharded run.
+One latency-bound collective of ~1 KB per iteration on xGMI instead of an all-gather before and an all-reduce
+after the evaluation; there is no bulk exchange to overlap.  The temporal pair (i, i+1) is owned, for the loss
+value, by the rank that owns frame i.  Shards must start on window boundaries so that the per-window
+normalisers match the unsharded run.
 """
 from __future__ import annotations
 
@@ -32,6 +34,9 @@ def shard_range(num_frames, rank, world_size, window=None):
     return rank * per, (rank + 1) * per
 
 
+SHARED_NAMES = ("betas", "log_beta_scales")
+
+
 class ShardedFitter:
     """Wraps a local fitter (FusedFitter protocol: evaluate / apply_adam / shared_grad / boundary_records /
     halo_prev / halo_next / trainable / begin_stage / losses) for rank `rank` of `world_size`."""
@@ -40,29 +45,58 @@ class ShardedFitter:
         self.fitter = local_fitter
         self.rank, self.world, self.group = rank, world_size, group
         self._gather = None
+        self._halo_valid = False
 
     def begin_stage(self, stage_id):
         self.fitter.begin_stage(stage_id)
 
-    def exchange_halos(self):
+    def invalidate_halos(self):
+        """call after changing per-frame parameters behind the fitter's back (e.g. load_checkpoint)"""
+        self._halo_valid = False
+
+    def _set_halos(self, records):
         f = self.fitter
-        rec = f.boundary_records().reshape(-1)          # (2*108,)
-        if self._gather is None or self._gather.numel() != self.world * 216:
-            self._gather = torch.empty(self.world * 216, device=rec.device, dtype=rec.dtype)
-        dist.all_gather_into_tensor(self._gather, rec, group=self.group)
-        g = self._gather.view(self.world, 2, 108)
-        f.halo_prev = g[self.rank - 1, 1].contiguous() if self.rank > 0 else None
-        f.halo_next = g[self.rank + 1, 0].contiguous() if self.rank + 1 < self.world else None
+        f.halo_prev = records[self.rank - 1, 1].contiguous() if self.rank > 0 else None
+        f.halo_next = records[self.rank + 1, 0].contiguous() if self.rank + 1 < self.world else None
+        self._halo_valid = True
+
+    def exchange_halos(self):
+        """stand-alone halo exchange (first iteration, or after invalidate_halos)"""
+        rec = self.fitter.boundary_records().reshape(-1)          # (2*108,)
+        out = torch.empty(self.world * rec.numel(), device=rec.device, dtype=rec.dtype)
+        dist.all_gather_into_tensor(out, rec, group=self.group)
+        self._set_halos(out.view(self.world, 2, 108))
 
     def step(self, weights, w_temp, lr, stage_id):
         f = self.fitter
         names = f.trainable(stage_id)
-        if self.world > 1 and float(w_temp) > 0.0:
+        if self.world == 1:
+            f.evaluate(weights, w_temp, stage_id, want=names)
+            f.apply_adam(names, lr)
+            return f.losses
+        if not self._halo_valid:
             self.exchange_halos()
         f.evaluate(weights, w_temp, stage_id, want=names)
-        if self.world > 1 and ("betas" in names or "log_beta_scales" in names):
-            dist.all_reduce(f.shared_grad(), op=dist.ReduceOp.SUM, group=self.group)
-        f.apply_adam(names, lr)
+        local = tuple(k for k in names if k not in SHARED_NAMES)
+        shared = tuple(k for k in names if k in SHARED_NAMES)
+        first = True
+        if local:
+            f.apply_adam(local, lr)
+            first = False
+        sg = f.shared_grad()
+        rec = f.boundary_records().reshape(-1)
+        payload = torch.cat([sg, rec.to(sg.dtype)])
+        if self._gather is None or self._gather.numel() != self.world * payload.numel() or self._gather.dtype != payload.dtype:
+            self._gather = torch.empty(self.world * payload.numel(), device=payload.device, dtype=payload.dtype)
+        dist.all_gather_into_tensor(self._gather, payload, group=self.group)
+        g = self._gather.view(self.world, payload.numel())
+        if shared:
+            total = g[0, : sg.numel()].clone()
+            for r in range(1, self.world):                     # rank order: same bits on every rank
+                total += g[r, : sg.numel()]
+            sg.copy_(total)
+            f.apply_adam(shared, lr, advance=first)
+        self._set_halos(g[:, sg.numel():].reshape(self.world, 2, 108).to(rec.dtype))
         return f.losses
 
     def global_losses(self):

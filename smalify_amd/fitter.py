@@ -129,8 +129,10 @@ class FusedFitter:
                         losses=self.losses, grads=self.g, want=want, **outs)
         return self.losses
 
-    def apply_adam(self, names, lr):
-        self.step_count += 1
+    def apply_adam(self, names, lr, advance=True):
+        """Adam on the trainable tensors `names`; advance=False: a second group of tensors within the same iteration"""
+        if advance:
+            self.step_count += 1
         for s, t in self._segments(names):
             eng.adam_step(self.flat[s:t], self.grad[s:t], self.exp_avg[s:t], self.exp_avg_sq[s:t], lr, self.step_count)
 

@@ -73,7 +73,7 @@ class OracleLocalFitter:
             self._shared = torch.cat([self.grads["betas"], self.grads["log_beta_scales"]]).contiguous()
         return self.losses
 
-    def apply_adam(self, names, lr):
+    def apply_adam(self, names, lr, advance=True):   # the oracle's Adam counts steps per tensor
         so = self.so
         if self.opt is None:
             self.opt = so.Adam(so.PARAM_ORDER, lr=lr)
