@@ -1014,8 +1014,8 @@ __global__ void __launch_bounds__(256)
 raster_band_kernel(int S, int M, int window, float w_sil, unsigned long long* __restrict__ gacc,
                    unsigned* __restrict__ bcnt, const float2* __restrict__ blist,
                    const float* __restrict__ tsil, float* __restrict__ sil_out, float2* __restrict__ gz,
-                   int* __restrict__ qcount, int* __restrict__ queue, const int* __restrict__ bqueue,
-                   long long* __restrict__ bloss /*[gridDim.x]: weighted |sil - target| per block in 2^-44 fixed point, or null*/) {
+                   float2* __restrict__ zband, int* __restrict__ qcount, int* __restrict__ queue,
+                   const int* __restrict__ bqueue, long long* __restrict__ bloss /*[gridDim.x]: weighted |sil - target| per block in 2^-44 fixed point, or null*/) {
   static_assert(kBandCap == 32, "one band entry per lane of a half-wave");
   __shared__ __attribute__((aligned(16))) float zs[8][32];
   __shared__ float red[16];
@@ -1073,6 +1073,14 @@ raster_band_kernel(int S, int M, int window, float w_sil, unsigned long long* __
           gx = -wn * sgn * alpha * (1.0f / kSigma);
         }
         gz[pi] = make_float2(gx, zin);
+        // re-centre the pixel's bounds on the depth of its K-th nearest as just determined (zin), keeping the
+        // half-width: the band then follows the surface from iteration to iteration instead of waiting where the last
+        // selection left it until the drift has used up the margin.  Bounds are hints -- any value is valid.
+        const float2 zb = zband[pi];
+        if (zb.y < kInf) {
+          const float shift = zin - 0.5f * (zb.x + zb.y);
+          zband[pi] = make_float2(zb.x + shift, zb.y + shift);
+        }
       } else {
         queue[atomicAdd(&qcount[0], 1)] = gp;
       }
