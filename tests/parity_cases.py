@@ -108,7 +108,8 @@ def _sil_metrics(sil_hip, sil_or):
             "sil_frac_gt_1e-4": float((d > 1e-4).mean()), "sil_frac_gt_1e-3": float((d > 1e-3).mean())}
 
 
-def case_render(M=2, S=64, z=1.45, seed=11):
+def case_render(M=2, S=64, z=1.45, seed=11, shrink=1.0):
+    """shrink < 1 scales the mesh about its centroid: every face then lands on the same few pixels"""
     md, om, _ = get_model()
     e, _, _ = get_engine(8, S)
     p = random_pose(M, seed, z=z)
@@ -117,7 +118,11 @@ def case_render(M=2, S=64, z=1.45, seed=11):
         vo, jo, _, _ = so.smal_forward(om, torch.from_numpy(np.tile(p["betas"], (M, 1))).double(),
                                        torch.from_numpy(theta).double(),
                                        torch.from_numpy(np.tile(p["log_beta_scales"], (M, 1))).double())
-    verts = (vo + torch.from_numpy(p["trans"]).double()[:, None]).float()       # float32 inputs for both
+    verts = vo + torch.from_numpy(p["trans"]).double()[:, None]
+    if shrink != 1.0:
+        c = verts.mean(1, keepdim=True)
+        verts = c + shrink * (verts - c)
+    verts = verts.float()                                                          # float32 inputs for both
     pts = (jo + torch.from_numpy(p["trans"]).double()[:, None])[:, so.CANONICAL].float()
     sil, proj = e.render_forward(verts.cuda().contiguous(), pts.cuda().contiguous())
     status = e.status()

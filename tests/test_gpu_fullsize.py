@@ -113,6 +113,18 @@ def test_renderer_other_sizes(M, S, z, seed):
     assert m["render_dverts_rel"] < 1e-2, m
 
 
+def test_renderer_thousands_of_candidates_per_pixel():
+    """A mesh shrunk to about a pixel: all 7774 faces are candidates of the same few pixels.  This overflows every
+    on-chip capacity of the selection kernel (1024 candidates, 2048 covering faces, 1024 union boxes), so its
+    re-evaluating fallback paths decide the K = 100 nearest."""
+    m = pc.case_render(1, 64, 1.45, 37, shrink=0.02)
+    assert m["render_status"] == 0
+    assert m["render_oracle_max_faces_per_pixel"] > 2048, m
+    assert m["sil_maxabs"] < 2e-3, m
+    # the 100 nearest of thousands of nearly coplanar candidates: float32 vs float64 depth ties flip a few of them
+    assert m["render_dverts_rel"] < 5e-2, m
+
+
 def test_renderer_mesh_off_screen():
     """no face box on screen: empty active region, silhouette exactly 0, zero vertex gradient"""
     md, om, _ = pc.get_model()
