@@ -1026,14 +1026,19 @@ raster_band_kernel(int S, int M, int window, float w_sil, unsigned long long* __
   const int nb = qcount[1];
   const int npix = S * S;
   long long lacc = 0;
-  for (int j = blockIdx.x * 8 + hw; j < nb; j += gridDim.x * 8) {
-    const int gp = bqueue[j];
+  const int jstep = gridDim.x * 8;
+  int gp_next = (blockIdx.x * 8 + hw < nb) ? bqueue[blockIdx.x * 8 + hw] : 0;
+  for (int j = blockIdx.x * 8 + hw; j < nb; j += jstep) {
+    const int gp = gp_next;
+    if (j + jstep < nb) gp_next = bqueue[j + jstep];    // next pixel's id in flight during this one
     const size_t pi = (size_t)gp;
+    // everything this pixel needs in one round trip (the list slot is read whether or not it is occupied)
     const unsigned long long vb = gacc[pi];
     const int b = (int)bcnt[pi];
     const float ts = tsil ? tsil[pi] : 0.f;
-    float2 v = make_float2(kInf, 0.f);
-    if (hl < b) v = blist[pi * kBandCap + hl];
+    const float2 zb_old = zband[pi];
+    float2 v = blist[pi * kBandCap + hl];
+    if (hl >= b) v = make_float2(kInf, 0.f);
     const int need = min(K - (int)(vb >> kCountShift), b);
     if (hl == 0) { gacc[pi] = 0ull; bcnt[pi] = 0u; }        // zero for the next sweep
     zs[hw][hl] = v.x;
@@ -1076,10 +1081,9 @@ raster_band_kernel(int S, int M, int window, float w_sil, unsigned long long* __
         // re-centre the pixel's bounds on the depth of its K-th nearest as just determined (zin), keeping the
         // half-width: the band then follows the surface from iteration to iteration instead of waiting where the last
         // selection left it until the drift has used up the margin.  Bounds are hints -- any value is valid.
-        const float2 zb = zband[pi];
-        if (zb.y < kInf) {
-          const float shift = zin - 0.5f * (zb.x + zb.y);
-          zband[pi] = make_float2(zb.x + shift, zb.y + shift);
+        if (zb_old.y < kInf) {
+          const float shift = zin - 0.5f * (zb_old.x + zb_old.y);
+          zband[pi] = make_float2(zb_old.x + shift, zb_old.y + shift);
         }
       } else {
         queue[atomicAdd(&qcount[0], 1)] = gp;
