@@ -152,11 +152,15 @@ def main():
 
     W = np.array(config.OPT_WEIGHTS).T
 
-    def run(fitter, iters_per_stage):
+    def run(fitter, iters_per_stage, stage_seconds=None):
         for stage_id, its in enumerate(iters_per_stage):
             fitter.begin_stage(stage_id)
+            t_stage = time.perf_counter()
             for _ in range(its):
                 fitter.step(W[stage_id][:6], float(W[stage_id][6]), float(W[stage_id][8]), stage_id)
+            if stage_seconds is not None:      # per-stage rates: one device sync per stage, 4 in the run
+                torch.cuda.synchronize()
+                stage_seconds.append(time.perf_counter() - t_stage)
 
     def sync():
         if world > 1:
@@ -173,7 +177,8 @@ def main():
     base.e.profile_begin(args.steps, PROFILE_STRIDE)
     sync()
     t0 = time.perf_counter()
-    run(fitter, sched)
+    stage_seconds = []
+    run(fitter, sched, stage_seconds)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -215,6 +220,8 @@ def main():
                                    "reference 4-stage schedule scaled to %d iterations %s, scene=%s"
                                    % (NUM_FRAMES, S, S, WINDOW, args.steps, sched, args.scene),
                        "frames": NUM_FRAMES, "image_size": S, "window": WINDOW, "parallelism": "frames/%d" % world},
+            "per_stage_iterations_per_s": {"stage%d" % i: (sched[i] / stage_seconds[i] if stage_seconds[i] > 0 else None)
+                                           for i in range(len(sched))},
             "roofline": {"bound": "hbm", "kernel": {"raster_sweep": "raster_sweep_kernel", "raster_select": "raster_select_kernel", "raster_resolve": "raster_resolve_kernel", "raster_bwd": "raster_bwd_kernel"}.get(dom_name), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": dom},
