@@ -89,7 +89,7 @@ struct AssembleArgs {
   const float* loss_part;
   const float* loss_betas;
   const float* tile_loss;
-  const long long* qloss;  // weighted silhouette loss of the queued pixels, one 2^-44 fixed-point partial per band / select block
+  const long long* qloss;  // weighted silhouette loss of the queued pixels, one 2^-40 fixed-point partial per band / select block
   int nqblk;
   float* lpart;            // [kAsmLoss] partial sums of the silhouette loss (assemble_kernel)
   long long* qpart;        // [kAsmLoss] integer partial sums of the queue kernels' loss

@@ -911,9 +911,9 @@ raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, const float* 
 }
 
 // The queues of the band / select kernels are filled in a non-deterministic order, so which block sums which pixel
-// varies from run to run: their loss partials are kept as 2^-44 fixed-point integers (integer adds commute), which
+// varies from run to run: their loss partials are kept as 2^-40 fixed-point integers (integer adds commute), which
 // makes the reported loss bit-reproducible like everything else.
-constexpr float kLossFix = 17592186044416.0f;   // 2^44
+constexpr float kLossFix = 1099511627776.0f;    // 2^40: a weighted per-pixel loss of 1 over 8M pixels still fits int64
 __device__ __forceinline__ long long wave_sum_i64(long long v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -1015,7 +1015,7 @@ raster_band_kernel(int S, int M, int window, float w_sil, unsigned long long* __
                    unsigned* __restrict__ bcnt, const float2* __restrict__ blist,
                    const float* __restrict__ tsil, float* __restrict__ sil_out, float2* __restrict__ gz,
                    float2* __restrict__ zband, int* __restrict__ qcount, int* __restrict__ queue,
-                   const int* __restrict__ bqueue, long long* __restrict__ bloss /*[gridDim.x]: weighted |sil - target| per block in 2^-44 fixed point, or null*/) {
+                   const int* __restrict__ bqueue, long long* __restrict__ bloss /*[gridDim.x]: weighted |sil - target| per block in 2^-40 fixed point, or null*/) {
   static_assert(kBandCap == 32, "one band entry per lane of a half-wave");
   __shared__ __attribute__((aligned(16))) float zs[8][32];
   __shared__ float red[16];
@@ -1115,7 +1115,7 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
                      const int4* __restrict__ brect, const int2* __restrict__ fbox, const int* __restrict__ qcount,
                      const int* __restrict__ queue, const float* __restrict__ tsil,
                      float* __restrict__ sil_out, float2* __restrict__ gz, float2* __restrict__ zband,
-                     long long* __restrict__ qloss /*[gridDim.x]: weighted |sil - target| per block in 2^-44 fixed point, or null*/, int dbg) {
+                     long long* __restrict__ qloss /*[gridDim.x]: weighted |sil - target| per block in 2^-40 fixed point, or null*/, int dbg) {
   __shared__ unsigned hist[kSelWaves][256];
   __shared__ float2 cand[kSelWaves][kCandCap];
   __shared__ unsigned short fids[kSelWaves][kCoverCap];
