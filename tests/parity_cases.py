@@ -303,3 +303,37 @@ def case_cache_consistency(M=4, S=64, window=3, stage=2, z=1.45, steps=6, seed=2
         for k in ga:
             grad_rel = max(grad_rel, rel(ga[k], gb[k]))
     return {"loss_rel_max": loss_rel, "grad_rel_max": grad_rel, "status": e_a.status() | e_b.status()}
+
+
+def case_sil_trajectory(M=4, S=64, window=2, iters=8, seed=21):
+    """The full loop with the silhouette on (stage-2 weights, lr 5e-4): FusedFitter on the GPU vs the oracle's loss +
+    autograd + Adam on the CPU, same start, same targets.  Returns the per-tensor relative differences after `iters`
+    iterations and the loss histories."""
+    from smalify_amd import fitter as fit
+    W = np.array(cfg.OPT_WEIGHTS).T
+    stage = 2
+    weights, w_temp, lr = W[stage][:6].copy(), float(W[stage][6]), float(W[stage][8])
+    e, prob, cur, tg = make_problem(M, S, window, seed)
+    names = so.trainable_names(stage)
+    # oracle loop
+    params = {k: torch.from_numpy(v).double() for k, v in cur.items()}
+    opt = so.Adam(so.PARAM_ORDER, lr=lr)
+    hist_o = []
+    for _ in range(iters):
+        total, sums, grads = so.loss_and_grads(prob, params, weights, w_temp, names)
+        opt.step(params, grads)
+        hist_o.append(float(total))
+    # device loop (betas / limb scales start from the perturbed values, as in the oracle)
+    f = fit.FusedFitter(e, tg["tj"], tg["vis"], tg["tsil"], window, True, cur["betas"], cur["log_beta_scales"])
+    for k in ("global_rotation", "joint_rotations", "trans"):
+        f.p[k].copy_(dev(cur[k]))
+    f.begin_stage(stage)
+    hist = []
+    for _ in range(iters):
+        f.step(weights, w_temp, lr, stage)
+        hist.append(float(f.losses.double().sum().item()))
+    out = {"traj_loss_rel_max": float(np.max(np.abs(np.array(hist) - np.array(hist_o)) / np.abs(np.array(hist_o)))),
+           "traj_status": e.status()}
+    for k in ("betas", "log_beta_scales", "global_rotation", "joint_rotations", "trans"):
+        out["traj_%s_rel" % k] = rel(f.p[k].cpu().numpy().reshape(params[k].shape), params[k].numpy())
+    return out

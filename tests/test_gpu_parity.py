@@ -96,3 +96,14 @@ def test_raster_cache_never_changes_results():
         assert m["loss_rel_max"] < 2e-6, m
         assert m["grad_rel_max"] < 2e-5, m
         assert m["status"] == 0
+
+
+def test_fit_loop_with_silhouette_follows_the_oracle():
+    """8 iterations of the whole loop with the silhouette term on (cached depth bounds included): losses and parameters
+    against the oracle's loss + autograd + Adam.  north_star's bar for parameters is 1e-4 relative L2."""
+    m = pc.case_sil_trajectory()
+    assert m["traj_status"] == 0
+    assert m["traj_loss_rel_max"] < 1e-4, m
+    for k, v in m.items():
+        if k.endswith("_rel") and k != "traj_loss_rel_max":
+            assert v < 1e-4, (k, v, m)
