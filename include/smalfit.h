@@ -110,6 +110,13 @@ int smalfit_rodrigues_backward(void* stream, int count, const float* theta, cons
  * points (M,P,3) -> proj_points (M,P,2) as (row, col) screen coordinates; points may be NULL */
 int smalfit_render_forward(smalfit_engine* engine, void* stream, int M, const float* verts,
                            const float* points, int P, float* sil, float* proj_points);
+/* Renderer.forward(render_texture=True), colour branch (p3d_renderer.py:41-59,70-72): hard rasterisation
+ * (blur_radius 0, faces_per_pixel 1) + HardPhongShader, one point light at (0,0,3), constant vertex colour `rgb`
+ * (host, 3 floats in [0,1]; the reference uses config.MESH_COLOR / 255), white background.  Visualisation only: no
+ * gradient.  verts [M][V][3] world space with the translation applied; image [M][3][S][S]. */
+int smalfit_render_color(smalfit_engine* engine, void* stream, int num_frames, const float* verts, const float* rgb /*host*/,
+                         float* image);
+
 /* adjoint wrt verts given the saved silhouette and dL/dsil (M,S,S) */
 int smalfit_render_backward(smalfit_engine* engine, void* stream, int M, const float* verts,
                             const float* sil, const float* dsil, float* dverts);

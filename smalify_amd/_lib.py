@@ -63,6 +63,7 @@ SIGNATURES = {
     "smalfit_rodrigues": (_I, [_VP, _I, _VP, _VP]),
     "smalfit_rodrigues_backward": (_I, [_VP, _I, _VP, _VP, _VP]),
     "smalfit_render_forward": (_I, [_VP, _VP, _I, _VP, _VP, _I, _VP, _VP]),
+    "smalfit_render_color": (_I, [_VP, _VP, _I, _VP, _VP, _VP]),
     "smalfit_render_backward": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP]),
     "smalfit_project_points_backward": (_I, [_VP, _I, _I, _VP, _VP, _VP]),
     "smalfit_fit_eval": (_I, [_VP, _VP, C.POINTER(FitArgs)]),

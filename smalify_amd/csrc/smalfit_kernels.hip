@@ -1428,6 +1428,111 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K5': colour render for visualisation (p3d_renderer.py:41-59,70-72: blur_radius 0, faces_per_pixel 1, HardPhongShader,
+// one point light at (0,0,3), constant vertex colour, white background).  Not on the optimisation path.
+//   vnormal_kernel      pytorch3d Meshes.verts_normals_packed (area-weighted incident face normals, normalised)
+//   color_zbuf_kernel   face-parallel z-buffer: (order-preserving depth key << 32 | face) with one 64-bit atomicMin
+//   color_shade_kernel  thread per pixel: screen-space barycentrics of the winning face, Phong terms
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+vnormal_kernel(ModelDev m, int M, const float* __restrict__ verts /*[M][3][Vp] world*/, float* __restrict__ vn /*[M][3][Vp]*/) {
+  const int v = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y, Vp = m.Vp;
+  if (v >= Vp) return;
+  const float* p = verts + (size_t)n * 3 * Vp;
+  float acc[3] = {0.f, 0.f, 0.f};
+  if (v < m.V) {
+    for (int i = m.vf_off[v]; i < m.vf_off[v + 1]; ++i) {
+      const int f = m.vf_idx[i] / 3;
+      const int i0 = m.faces[f * 3], i1 = m.faces[f * 3 + 1], i2 = m.faces[f * 3 + 2];
+      const float ux = p[i1] - p[i0], uy = p[Vp + i1] - p[Vp + i0], uz = p[2 * Vp + i1] - p[2 * Vp + i0];
+      const float wx = p[i2] - p[i0], wy = p[Vp + i2] - p[Vp + i0], wz = p[2 * Vp + i2] - p[2 * Vp + i0];
+      acc[0] += uy * wz - uz * wy; acc[1] += uz * wx - ux * wz; acc[2] += ux * wy - uy * wx;
+    }
+    const float inv = 1.0f / fmaxf(sqrtf(acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2]), 1e-6f);
+    acc[0] *= inv; acc[1] *= inv; acc[2] *= inv;
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) vn[((size_t)n * 3 + a) * Vp + v] = acc[a];
+}
+
+__global__ void __launch_bounds__(256)
+color_zbuf_kernel(ModelDev m, int S, const float* __restrict__ proj, unsigned long long* __restrict__ zbuf /*[M][S*S], preset to ~0*/) {
+  const int n = blockIdx.y, f = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15, Vp = m.Vp;
+  if (f >= m.F) return;
+  const float* px = proj + (size_t)n * 3 * Vp;
+  const int i0 = m.faces[f * 3], i1 = m.faces[f * 3 + 1], i2 = m.faces[f * 3 + 2];
+  const float ax = px[i0], ay = px[Vp + i0], az = px[2 * Vp + i0];
+  const float bx = px[i1], by = px[Vp + i1], bz = px[2 * Vp + i1];
+  const float cx = px[i2], cy = px[Vp + i2], cz = px[2 * Vp + i2];
+  FaceRec r;
+  if (!make_face_rec(ax, ay, az, bx, by, bz, cx, cy, cz, r)) return;
+  const float xlo = fminf(ax, fminf(bx, cx)), xhi = fmaxf(ax, fmaxf(bx, cx));
+  const float ylo = fminf(ay, fminf(by, cy)), yhi = fmaxf(ay, fmaxf(by, cy));
+  if (!(xlo == xlo && xhi == xhi && ylo == ylo && yhi == yhi) || xhi < -1.0f || xlo > 1.0f || yhi < -1.0f || ylo > 1.0f) return;
+  const float fs = (float)S;
+  const int c0 = (int)fminf(fmaxf(floorf(((1.0f - xhi) * fs - 1.0f) * 0.5f), 0.f), fs - 1.f);
+  const int c1 = (int)fminf(fmaxf(ceilf(((1.0f - xlo) * fs - 1.0f) * 0.5f), 0.f), fs - 1.f);
+  const int r0 = (int)fminf(fmaxf(floorf(((1.0f - yhi) * fs - 1.0f) * 0.5f), 0.f), fs - 1.f);
+  const int r1 = (int)fminf(fmaxf(ceilf(((1.0f - ylo) * fs - 1.0f) * 0.5f), 0.f), fs - 1.f);
+  const int bw = c1 - c0 + 1, npx = bw * (r1 - r0 + 1);
+  const float inv_s = 1.0f / fs;
+  unsigned long long* zb = zbuf + (size_t)n * S * S;
+  for (int q = sub; q < npx; q += 16) {
+    const int row = r0 + q / bw, col = c0 + q % bw;
+    PixEval e;
+    if (!face_pixel_eval(r, pix_to_ndc(col, inv_s), pix_to_ndc(row, inv_s), e) || !e.inside) continue;
+    atomicMin(&zb[row * S + col], ((unsigned long long)orderable(e.pz) << 32) | (unsigned)f);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+color_shade_kernel(ModelDev m, int S, const float* __restrict__ proj, const float* __restrict__ verts /*[M][3][Vp] world*/,
+                   const float* __restrict__ vn, const unsigned long long* __restrict__ zbuf, float cr, float cg, float cb,
+                   float* __restrict__ image /*[M][3][S][S]*/) {
+  const int pix = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y, Vp = m.Vp;
+  if (pix >= S * S) return;
+  float rgb[3] = {1.0f, 1.0f, 1.0f};                       // BlendParams default background
+  const unsigned long long key = zbuf[(size_t)n * S * S + pix];
+  if (key != ~0ull) {
+    const int f = (int)(key & 0xffffffffull);
+    const int idx[3] = {m.faces[f * 3], m.faces[f * 3 + 1], m.faces[f * 3 + 2]};
+    const float* px = proj + (size_t)n * 3 * Vp;
+    FaceRec r;
+    make_face_rec(px[idx[0]], px[Vp + idx[0]], px[2 * Vp + idx[0]], px[idx[1]], px[Vp + idx[1]], px[2 * Vp + idx[1]],
+                  px[idx[2]], px[Vp + idx[2]], px[2 * Vp + idx[2]], r);
+    const float inv_s = 1.0f / (float)S;
+    const float dx = pix_to_ndc(pix % S, inv_s) - r.ax, dy = pix_to_ndc(pix / S, inv_s) - r.ay;
+    const float c1 = fmaf(dx, r.e1y, -(dy * r.e1x)), c2 = fmaf(dx, r.e2y, -(dy * r.e2x));
+    const float w[3] = {((c2 - c1) + r.area) * r.inv_den, -c2 * r.inv_den, c1 * r.inv_den};
+    const float* pw = verts + (size_t)n * 3 * Vp;
+    const float* pn = vn + (size_t)n * 3 * Vp;
+    float pos[3] = {0.f, 0.f, 0.f}, nr[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { pos[a] = fmaf(w[k], pw[a * Vp + idx[k]], pos[a]); nr[a] = fmaf(w[k], pn[a * Vp + idx[k]], nr[a]); }
+    const float inn = 1.0f / fmaxf(sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]), 1e-6f);
+    nr[0] *= inn; nr[1] *= inn; nr[2] *= inn;
+    float ld[3] = {0.0f - pos[0], 0.0f - pos[1], 3.0f - pos[2]};           // PointLights(location = (0, 0, 3))
+    const float inl = 1.0f / fmaxf(sqrtf(ld[0] * ld[0] + ld[1] * ld[1] + ld[2] * ld[2]), 1e-6f);
+    ld[0] *= inl; ld[1] *= inl; ld[2] *= inl;
+    const float cosang = nr[0] * ld[0] + nr[1] * ld[1] + nr[2] * ld[2];
+    const float diffuse = 0.3f * fmaxf(cosang, 0.f);
+    float vd[3] = {0.0f - pos[0], 0.0f - pos[1], kCamDist - pos[2]};       // camera centre
+    const float inv_v = 1.0f / fmaxf(sqrtf(vd[0] * vd[0] + vd[1] * vd[1] + vd[2] * vd[2]), 1e-6f);
+    float va = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) va += vd[a] * inv_v * (-ld[a] + 2.0f * cosang * nr[a]);
+    const float alpha = (cosang > 0.f) ? fmaxf(va, 0.f) : 0.f;
+    const float spec = 0.2f * powf(alpha, 64.0f);
+    const float amb = 0.5f + diffuse;
+    rgb[0] = amb * cr + spec; rgb[1] = amb * cg + spec; rgb[2] = amb * cb + spec;
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) image[((size_t)n * 3 + a) * S * S + pix] = rgb[a];
+}
+
 // gz = (dsil * (-(1 - sil) / sigma), zthr)   (component API: arbitrary upstream gradient)
 __global__ void gpix_from_dsil_kernel(size_t total, const float* __restrict__ sil, const float* __restrict__ dsil,
                                       float2* __restrict__ gz) {

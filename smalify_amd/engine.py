@@ -213,6 +213,17 @@ class Engine:
                                               _ptr(proj)), "smalfit_render_forward")
         return sil, proj
 
+    def render_color(self, verts, rgb):
+        """Hard-Phong colour render (visualisation, no gradient): verts (M,V,3) world incl. translation, rgb 3 floats in
+        [0,1] -> (M,3,S,S)."""
+        M = int(verts.shape[0])
+        S = self.image_size
+        image = torch.empty(M, 3, S, S, device=verts.device)
+        col = np.ascontiguousarray(np.asarray(rgb, dtype=np.float32).reshape(3))
+        check(self.lib.smalfit_render_color(self.handle, _stream(), M, _ptr(verts), col.ctypes.data, _ptr(image)),
+              "smalfit_render_color")
+        return image
+
     def render_backward(self, verts, sil, dsil):
         dverts = torch.empty_like(verts)
         check(self.lib.smalfit_render_backward(self.handle, _stream(), int(verts.shape[0]), _ptr(verts), _ptr(sil),

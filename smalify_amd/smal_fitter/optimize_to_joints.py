@@ -30,6 +30,24 @@ def write_ply(path, vertices, faces):
         fh.write(rec.tobytes())
 
 
+def write_png(path, image):
+    """8-bit RGB PNG with nothing but zlib (replaces imageio.imsave, optimize_to_joints.py:45)"""
+    import struct
+    import zlib
+    img = np.ascontiguousarray(image, dtype=np.uint8)
+    h, w, c = img.shape
+    assert c == 3
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), img.reshape(h, w * 3)], axis=1).tobytes()   # filter type 0 per row
+
+    def chunk(tag, data):
+        body = tag + data
+        return struct.pack(">I", len(data)) + body + struct.pack(">I", zlib.crc32(body) & 0xFFFFFFFF)
+
+    with open(path, "wb") as fh:
+        fh.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0))
+                 + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
 class ImageExporter:
     """same directory layout and file names as the reference's exporter (optimize_to_joints.py:25-53)"""
 
@@ -45,6 +63,7 @@ class ImageExporter:
 
     def export(self, collage_np, batch_id, global_id, img_parameters, vertices, faces):
         stem = os.path.join(self.output_dirs[global_id], "st{0}_ep{1}".format(self.stage_id, self.epoch_name))
+        write_png(stem + ".png", collage_np)
         with open(stem + ".pkl", "wb") as f:
             pkl.dump(img_parameters, f)
         v = vertices[batch_id]

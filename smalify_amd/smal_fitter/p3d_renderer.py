@@ -4,8 +4,9 @@
 
 Fixed camera (look_at_view_transform(2.7,0,0) + OpenGL perspective fov 60), soft silhouette with
 sigma = 1e-4, blur = log(1/1e-4 - 1)*sigma, 100 faces per pixel, keypoints returned as (row, col):
-all HIP (smalfit_render_forward / _backward, smalfit_project_points_backward).  The colour render
-(render_texture=True, used only for visualisation collages) is not part of the fitting path."""
+all HIP (smalfit_render_forward / _backward, smalfit_project_points_backward).  render_texture=True adds the
+colour image of the reference's second renderer (hard rasterisation + HardPhongShader, mesh colour
+config.MESH_COLOR, white background; smalfit_render_color) -- visualisation only, it carries no gradient."""
 from __future__ import annotations
 
 import torch
@@ -66,11 +67,14 @@ class Renderer(nn.Module):
         return proj
 
     def forward(self, vertices, points, faces, render_texture=False):
-        if render_texture:
-            raise NotImplementedError("the colour (hard Phong) render is visualisation-only and not provided")
         e = self._engine(vertices.shape[0])
         if faces is not None and faces.shape[-2] != e.model.num_faces:
             raise ValueError("faces do not match the SMAL topology the rasteriser was built for")
         sil = _Silhouette.apply(self, vertices)
         proj = _Project.apply(self, points)
+        if render_texture:
+            from .. import config
+            with torch.no_grad():
+                color = e.render_color(vertices.detach().contiguous().float(), [c / 255.0 for c in config.MESH_COLOR])
+            return sil.unsqueeze(1), proj, color
         return sil.unsqueeze(1), proj

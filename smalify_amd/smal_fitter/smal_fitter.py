@@ -178,9 +178,34 @@ class SMALFitter(nn.Module):
                             "trans": self.trans[i].cpu().numpy()})
             return out
 
+    @staticmethod
+    def _draw_joints(images, landmarks, visible=None):
+        """Marks keypoints on (B,3,S,S) images in [0,1]: landmarks (B,25,2) as (row, col).  Stands in for the reference's
+        cv2 marker drawer (draw_smal_joints.py:22-46): plus-shaped marks, one hue per limb group; invisible joints are
+        parked along the top edge like there."""
+        imgs = np.transpose(np.asarray(images.detach().cpu().numpy(), np.float32), (0, 2, 3, 1)).copy()
+        lm = np.asarray(landmarks.detach().cpu().numpy())
+        vis = np.ones(lm.shape[:2], bool) if visible is None else np.asarray(visible.detach().cpu().numpy()) > 0
+        S = imgs.shape[1]
+        for b in range(imgs.shape[0]):
+            parked = 0
+            for j in range(lm.shape[1]):
+                h = (j // 3) / 9.0
+                col = np.clip(np.abs((h * 6.0 + np.array([0.0, 4.0, 2.0])) % 6.0 - 3.0) - 1.0, 0.0, 1.0)
+                r, c = (int(round(lm[b, j, 0])), int(round(lm[b, j, 1]))) if vis[b, j] else (0, parked * 10)
+                parked += 0 if vis[b, j] else 1
+                for dr, dc in [(0, k) for k in range(-4, 5)] + [(k, 0) for k in range(-4, 5)]:
+                    rr, cc = r + dr, c + dc
+                    if 0 <= rr < S and 0 <= cc < S:
+                        imgs[b, rr, cc] = col
+        return torch.from_numpy(np.transpose(imgs, (0, 3, 1, 2)))
+
     def generate_visualization(self, image_exporter):
-        """Exports parameters and posed meshes like reference smal_fitter.py:209-272; the image collage itself
-        (colour render + cv2 overlays) is visualisation tooling and is replaced by a blank image."""
+        """reference smal_fitter.py:209-272: per frame a five-panel collage (target + keypoints | colour render +
+        projected keypoints | overlay | 1 - |silhouette error| | the mesh seen from behind), the parameter dict and the
+        posed mesh go to image_exporter.export.  The colour renders come from smalfit_render_color; the keypoint marks
+        are drawn in numpy instead of cv2."""
+        rot_y180 = torch.tensor([[-1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, -1.0]], device=self.device)
         for j in range(0, self.num_images, self.batch_size):
             batch_range = list(range(j, min(self.num_images, j + self.batch_size)))
             with torch.no_grad():
@@ -188,9 +213,23 @@ class SMALFitter(nn.Module):
                                    self.joint_rotations[batch_range] * self.rotation_mask], dim=1)
                 ls = self.log_beta_scales
                 ls = ls.expand(len(batch_range), 6) if ls.dim() == 1 else ls[batch_range]
-                verts, _, _, _ = self.smal_model(self.betas.expand(len(batch_range), self.n_betas).contiguous(),
-                                                 theta.contiguous(), betas_logscale=ls.contiguous())
-                verts = verts + self.trans[batch_range].unsqueeze(1)
-            blank = np.zeros((self.image_size, self.image_size * 5, 3), dtype=np.uint8)
+                verts, joints, _, _ = self.smal_model(self.betas.expand(len(batch_range), self.n_betas).contiguous(),
+                                                      theta.contiguous(), betas_logscale=ls.contiguous())
+                trans = self.trans[batch_range].unsqueeze(1)
+                verts = verts + trans
+                canonical = (joints + trans)[:, config.CANONICAL_MODEL_JOINTS]
+                sil, proj, rendered = self.renderer(verts, canonical, None, render_texture=True)
+                centre = verts.mean(dim=1, keepdim=True)
+                _, rev_proj, rev_rendered = self.renderer(((verts - centre) @ rot_y180.T).contiguous(),
+                                                          ((canonical - centre) @ rot_y180.T).contiguous(), None,
+                                                          render_texture=True)
+                rgb = self.rgb_imgs[batch_range].to(self.device).float()
+                vis = self.target_visibility[batch_range]
+                overlay = rendered * 0.8 + rgb * 0.2
+                sil_err = (1.0 - (self.sil_imgs[batch_range].reshape(sil.shape) - sil).abs()).expand(-1, 3, -1, -1).cpu()
+                collage = torch.cat([self._draw_joints(rgb, self.target_joints[batch_range], vis),
+                                     self._draw_joints(rendered, proj, vis), self._draw_joints(overlay, proj, vis),
+                                     sil_err, self._draw_joints(rev_rendered, rev_proj, vis)], dim=3)
             for batch_id, (global_id, params) in enumerate(zip(batch_range, self.frame_parameters(batch_range))):
-                image_exporter.export(blank, batch_id, global_id, params, verts, self.smal_model.f)
+                collage_np = (np.transpose(collage[batch_id].numpy(), (1, 2, 0)) * 255.0).astype(np.uint8)
+                image_exporter.export(collage_np, batch_id, global_id, params, verts, self.smal_model.f)

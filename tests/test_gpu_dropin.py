@@ -109,8 +109,16 @@ def test_renderer_module(md):
     assert np.abs(proj.detach().cpu().numpy() - proj_o.detach().numpy()).max() < 1e-3
     assert rel(verts.grad.cpu(), v64.grad) < 1e-2
     assert rel(pts.grad.cpu(), p64.grad) < 1e-5
-    with pytest.raises(NotImplementedError):
-        renderer(verts, pts, None, render_texture=True)
+    # colour branch (visualisation): hard Phong render against the oracle's restatement.  Pixels on a face boundary
+    # can go to a different face in float32; everywhere else the colours agree to rounding.
+    _, _, color = renderer(verts.detach(), pts.detach(), None, render_texture=True)
+    assert color.shape == (M, 3, S, S)
+    col_o = so.hard_phong_render(verts.detach().cpu().double(), om.faces, S, np.array(cfg.MESH_COLOR) / 255.0)
+    diff = np.abs(color.cpu().numpy() - col_o).max(axis=1)
+    assert (diff > 1e-3).mean() < 5e-3, (diff > 1e-3).mean()
+    assert np.median(diff) < 1e-5
+    covered = (col_o < 1.0).any(axis=1)
+    assert covered.mean() > 0.02 and ((color.cpu().numpy() < 1.0).any(axis=1) == covered).mean() > 0.998
 
 
 def _reference_style_loop(f, golden, vis_full):
@@ -213,3 +221,30 @@ def test_checkpoint_layout_roundtrip(golden, md, tmp_path):
         ref = golden["g9_loaded_" + k]
         assert np.allclose(getattr(g, k).detach().cpu().numpy(), ref, atol=1e-6), k
         assert np.allclose(f.p[k].cpu().numpy(), ref, atol=1e-6), k
+
+
+def test_generate_visualization_writes_the_reference_files(golden, md, tmp_path):
+    """SMALFitter.generate_visualization + ImageExporter (smal_fitter.py:209-272, optimize_to_joints.py:25-53): per
+    frame a five-panel collage .png (colour renders included), the parameter .pkl and the posed mesh .ply."""
+    import struct
+    import zlib
+    from smalify_amd.smal_fitter.optimize_to_joints import ImageExporter
+    f = _make_fitter(golden, md, 2)
+    N, S = f.num_images, f.image_size
+    names = ["%04d.png" % i for i in range(N)]
+    exporter = ImageExporter(str(tmp_path), names)
+    exporter.stage_id, exporter.epoch_name = 10, 0
+    f.generate_visualization(exporter)
+    for i in range(N):
+        stem = os.path.join(str(tmp_path), "%04d" % i, "st10_ep0")
+        assert os.path.getsize(stem + ".ply") > 80 + md.num_verts * 12
+        with open(stem + ".pkl", "rb") as fh:
+            assert sorted(pickle.load(fh)) == ["betas", "global_rotation", "joint_rotations", "log_betascale", "trans"]
+        blob = open(stem + ".png", "rb").read()
+        assert blob[:8] == b"\x89PNG\r\n\x1a\n"
+        w, h = struct.unpack(">II", blob[16:24])
+        assert (w, h) == (5 * S, S)
+        n = struct.unpack(">I", blob[33:37])[0]
+        rows = np.frombuffer(zlib.decompress(blob[41:41 + n]), np.uint8).reshape(h, 1 + 3 * w)[:, 1:].reshape(h, w, 3)
+        render_panel = rows[:, S:2 * S]
+        assert (render_panel != 255).any(axis=2).mean() > 0.01        # the mesh is visible on the white background
