@@ -712,8 +712,10 @@ __device__ __forceinline__ float prob_fast(float d) {
 __global__ void __launch_bounds__(256)
 face_bbox_kernel(ModelDev m, int S, const float* __restrict__ proj, int2* __restrict__ fbox,
                  float4* __restrict__ frec /*[M][F][3]*/, int4* __restrict__ brect /*[M][ceil(F/32)]*/,
-                 float* __restrict__ zc /*[M]*/, int* __restrict__ frect /*[M][4]: S - x0, x1 + 1, S - y0, y1 + 1 of the active region; 0 = empty*/) {
+                 float* __restrict__ zc /*[M]*/, int* __restrict__ frect /*[M][4]: S - x0, x1 + 1, S - y0, y1 + 1 of the active region; 0 = empty*/,
+                 int* __restrict__ qcount /*[2]: the select / band queue lengths, reset here for this evaluation*/) {
   const int f = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (blockIdx.x == 0 && n == 0 && threadIdx.x < 2) qcount[threadIdx.x] = 0;
   const int Vp = m.Vp;
   const float* px = proj + (size_t)n * 3 * Vp;
   // reference depth of the frame (mean over 64 spread vertices).  The rasteriser orders candidates by pz - zc, which
