@@ -664,11 +664,18 @@ constexpr int kSweepFaces = SMALFIT_SWEEP_FACES;   // faces per sweep block
 constexpr int kAccWin = SMALFIT_ACC_WIN;  // LDS accumulator window edge (pixels); outside: global atomics
 constexpr int kCountShift = 50;
 constexpr float kLogFix = 16777216.0f;    // 2^24
-constexpr int kBandCap = 32;              // per-pixel list of candidates between the two cached depth bounds
+constexpr int kBandCap = 64;              // per-pixel list of candidates between the two cached depth bounds
 #ifndef SMALFIT_BAND_FILL
 #define SMALFIT_BAND_FILL 30
 #endif
-constexpr int kBandFill = SMALFIT_BAND_FILL;   // the select kernel sizes the band to hold at most this many entries
+#ifndef SMALFIT_BAND_FILL_WIDE
+#define SMALFIT_BAND_FILL_WIDE 60
+#endif
+#ifndef SMALFIT_BAND_FILL_NARROW
+#define SMALFIT_BAND_FILL_NARROW 16
+#endif
+constexpr int kBandFill = SMALFIT_BAND_FILL;   // the select kernel sizes the band to hold at most this many entries ...
+constexpr int kBandFillWide = SMALFIT_BAND_FILL_WIDE, kBandFillNarrow = SMALFIT_BAND_FILL_NARROW;   // ... or these, by miss rate
 #ifndef SMALFIT_BAND_STAGE
 #define SMALFIT_BAND_STAGE 128
 #endif
@@ -713,9 +720,9 @@ __global__ void __launch_bounds__(256)
 face_bbox_kernel(ModelDev m, int S, const float* __restrict__ proj, int2* __restrict__ fbox,
                  float4* __restrict__ frec /*[M][F][3]*/, int4* __restrict__ brect /*[M][ceil(F/32)]*/,
                  float* __restrict__ zc /*[M]*/, int* __restrict__ frect /*[M][4]: S - x0, x1 + 1, S - y0, y1 + 1 of the active region; 0 = empty*/,
-                 int* __restrict__ qcount /*[2]: the select / band queue lengths, reset here for this evaluation*/) {
+                 int* __restrict__ qcount /*[3]: select / band queue lengths, pixels resolve sent to select; reset here*/) {
   const int f = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
-  if (blockIdx.x == 0 && n == 0 && threadIdx.x < 2) qcount[threadIdx.x] = 0;
+  if (blockIdx.x == 0 && n == 0 && threadIdx.x < 3) qcount[threadIdx.x] = 0;
   const int Vp = m.Vp;
   const float* px = proj + (size_t)n * 3 * Vp;
   // reference depth of the frame (mean over 64 spread vertices).  The rasteriser orders candidates by pz - zc, which
@@ -1000,6 +1007,7 @@ raster_resolve_kernel(int S, int M, int window, float w_sil, unsigned long long*
   }
   __syncthreads();
   if (t < 2) qbase[t] = qn[t] > 0 ? atomicAdd(&qcount[t], qn[t]) : 0;
+  if (t == 2 && qn[0] > 0) atomicAdd(&qcount[2], qn[0]);   // [2] stays fixed while the band kernel appends its failures to [0]
   __syncthreads();
   if (action == 1) queue[qbase[0] + slot] = (int)pi;
   else if (action == 2) bqueue[qbase[1] + slot] = (int)pi;
@@ -1018,8 +1026,8 @@ raster_band_kernel(int S, int M, int window, float w_sil, unsigned long long* __
                    const float* __restrict__ tsil, float* __restrict__ sil_out, float2* __restrict__ gz,
                    float2* __restrict__ zband, int* __restrict__ qcount, int* __restrict__ queue,
                    const int* __restrict__ bqueue, long long* __restrict__ bloss /*[gridDim.x]: weighted |sil - target| per block in 2^-40 fixed point, or null*/) {
-  static_assert(kBandCap == 32, "one band entry per lane of a half-wave");
-  __shared__ __attribute__((aligned(16))) float zs[8][32];
+  static_assert(kBandCap == 64, "two band entries per lane of a half-wave");
+  __shared__ __attribute__((aligned(16))) float zs[8][64];
   __shared__ float red[16];
   constexpr int K = kFacesPerPixel;
   constexpr unsigned long long kSumMask = (1ull << kCountShift) - 1ull;
@@ -1028,34 +1036,53 @@ raster_band_kernel(int S, int M, int window, float w_sil, unsigned long long* __
   const int nb = qcount[1];
   const int npix = S * S;
   long long lacc = 0;
+  // band population this evaluation's miss rate calls for (same rule as the selection kernel; qcount[2] does not
+  // change while this kernel runs, so the decision is the same in every run)
+  const float miss = (float)qcount[2] / (float)max(qcount[2] + nb, 1);
+  const int fill_target = (miss > 0.12f) ? kBandFillWide : ((miss > 0.02f) ? kBandFill : kBandFillNarrow);
   const int jstep = gridDim.x * 8;
   int gp_next = (blockIdx.x * 8 + hw < nb) ? bqueue[blockIdx.x * 8 + hw] : 0;
   for (int j = blockIdx.x * 8 + hw; j < nb; j += jstep) {
     const int gp = gp_next;
     if (j + jstep < nb) gp_next = bqueue[j + jstep];    // next pixel's id in flight during this one
     const size_t pi = (size_t)gp;
-    // everything this pixel needs in one round trip (the list slot is read whether or not it is occupied)
+    // everything this pixel needs in one round trip (list slots are read whether or not they are occupied); a lane
+    // holds entries hl and hl + 32 -- the second half only exists for wide bands (large parameter steps)
     const unsigned long long vb = gacc[pi];
     const int b = (int)bcnt[pi];
     const float ts = tsil ? tsil[pi] : 0.f;
     const float2 zb_old = zband[pi];
-    float2 v = blist[pi * kBandCap + hl];
+    float2 v = blist[pi * kBandCap + hl], u = blist[pi * kBandCap + 32 + hl];
     if (hl >= b) v = make_float2(kInf, 0.f);
+    if (hl + 32 >= b) u = make_float2(kInf, 0.f);
+    const bool wide = b > 32;                              // uniform over the half-wave
     const int need = min(K - (int)(vb >> kCountShift), b);
     if (hl == 0) { gacc[pi] = 0ull; bcnt[pi] = 0u; }        // zero for the next sweep
     zs[hw][hl] = v.x;
+    zs[hw][32 + hl] = u.x;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    int rank = 0;
+    int rank = 0, rank_u = 0;
 #pragma unroll
     for (int k4 = 0; k4 < 8; ++k4) {
       const float4 q = *reinterpret_cast<const float4*>(&zs[hw][k4 * 4]);
       rank += (q.x < v.x) + (q.y < v.x) + (q.z < v.x) + (q.w < v.x);
     }
-    const bool in = (hl < b) && (rank < need);
-    const unsigned long long pv = in ? (pack_candidate(v.y) & kSumMask) : 0ull;
+    if (wide) {
+#pragma unroll
+      for (int k4 = 0; k4 < 8; ++k4) {
+        const float4 q = *reinterpret_cast<const float4*>(&zs[hw][k4 * 4]);
+        const float4 p = *reinterpret_cast<const float4*>(&zs[hw][32 + k4 * 4]);
+        rank += (p.x < v.x) + (p.y < v.x) + (p.z < v.x) + (p.w < v.x);
+        rank_u += (q.x < u.x) + (q.y < u.x) + (q.z < u.x) + (q.w < u.x) + (p.x < u.x) + (p.y < u.x) + (p.z < u.x) + (p.w < u.x);
+      }
+    }
+    const bool in = (hl < b) && (rank < need), in_u = (hl + 32 < b) && (rank_u < need);
+    unsigned long long pv = in ? (pack_candidate(v.y) & kSumMask) : 0ull;
+    if (in_u) pv += pack_candidate(u.y) & kSumMask;
     int s_lo = (int)(pv & 0x1ffffffull), s_hi = (int)(pv >> 25);
-    float zin = in ? v.x : -kInf, zout = (hl < b && !in) ? v.x : kInf;
+    float zin = fmaxf(in ? v.x : -kInf, in_u ? u.x : -kInf);
+    float zout = fminf((hl < b && !in) ? v.x : kInf, (hl + 32 < b && !in_u) ? u.x : kInf);
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) {
       s_lo += __shfl_xor(s_lo, o, 32); s_hi += __shfl_xor(s_hi, o, 32);
@@ -1063,7 +1090,8 @@ raster_band_kernel(int S, int M, int window, float w_sil, unsigned long long* __
     }
     // ranks ignore ties: with a tie at the cut the number of entries <= zin is not `need`; let the selection decide
     const unsigned long long bal = __ballot((hl < b) && (v.x <= zin));
-    const int taken = __popc((unsigned)(bal >> (32 * (hw & 1))));
+    const unsigned long long bal_u = __ballot((hl + 32 < b) && (u.x <= zin));
+    const int taken = __popc((unsigned)(bal >> (32 * (hw & 1)))) + __popc((unsigned)(bal_u >> (32 * (hw & 1))));
     if (hl == 0) {
       if (taken == need && zin < zout) {
         const unsigned long long sum = (vb & kSumMask) + ((unsigned long long)s_hi << 25) + (unsigned long long)s_lo;
@@ -1081,11 +1109,12 @@ raster_band_kernel(int S, int M, int window, float w_sil, unsigned long long* __
         }
         gz[pi] = make_float2(gx, zin);
         // re-centre the pixel's bounds on the depth of its K-th nearest as just determined (zin), keeping the
-        // half-width: the band then follows the surface from iteration to iteration instead of waiting where the last
-        // selection left it until the drift has used up the margin.  Bounds are hints -- any value is valid.
+        // half-width (or narrowing it when it holds more candidates than the current pose motion calls for): the band
+        // follows the surface from iteration to iteration.  Bounds are hints -- any value is valid.
         if (zb_old.y < kInf) {
-          const float shift = zin - 0.5f * (zb_old.x + zb_old.y);
-          zband[pi] = make_float2(zb_old.x + shift, zb_old.y + shift);
+          float half = 0.5f * (zb_old.y - zb_old.x);
+          if (4 * b > 5 * fill_target) half *= (float)fill_target / (float)b;   // wider than the pose motion needs now
+          zband[pi] = make_float2(zin - half, zin + half);
         }
       } else {
         queue[atomicAdd(&qcount[0], 1)] = gp;
@@ -1131,6 +1160,12 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
   constexpr int RPI = 64 / kRectFaces;      // union boxes handled per wave iteration
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int nq = *qcount;
+  // how many candidates the new bands may hold: wide bands survive large parameter steps (stage 1) but cost list
+  // appends and band sorting in every later evaluation, narrow ones are cheap while the pose barely moves.  The share
+  // of bounded pixels that needed this kernel in the current evaluation decides.
+  const int nbandq = qcount[1];
+  const float miss = (float)nq / (float)max(nq + nbandq, 1);
+  const int band_fill = (miss > 0.12f) ? kBandFillWide : ((miss > 0.02f) ? kBandFill : kBandFillNarrow);
   const int nrect = (F + kRectFaces - 1) / kRectFaces;
   const float inv_s = 1.0f / (float)S;
   const int npix = S * S;
@@ -1394,11 +1429,12 @@ raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4*
     float blo = kInf, bhi = kInf;
     if (nc > K) {
       blo = bhi = zmid;
+      const int fill = band_fill;
       float delta = delta0;
       bool chosen = false;
 #pragma unroll
       for (int i = 0; i < kBandTries; ++i) {
-        if (!chosen && cbs[i] <= kBandFill && zk - delta < zk) {
+        if (!chosen && cbs[i] <= fill && zk - delta < zk) {
           blo = zk - delta; bhi = (cfs[i] == 0) ? kInf : zk + delta; chosen = true;
         }
         delta *= 0.5f;
