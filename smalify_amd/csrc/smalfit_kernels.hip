@@ -630,28 +630,30 @@ loss_kernel(LossArgs a) {
 // single block; betas/logscale shared across frames (fitter) -> grads are for the shared vectors.
 
 // ------------------------------------------------------------------------------------------------
-// K5: soft-silhouette rasteriser
+// K5: soft-silhouette rasteriser  (DESIGN.md section 4 has the measurements behind each choice)
 //
 // pytorch3d keeps, per pixel, only the faces_per_pixel = 100 candidates nearest in depth; with the
 // reference's head-on initial pose a pixel sees hundreds of candidates, so the truncation is first-class.
-// Measured on MI355X while designing this (64 frames, 256^2): a frame-wide sweep in which every face walks
-// its own blur-expanded pixel box (16 lanes per face, 4x4-pixel patches) costs 0.17-0.22 ms; evaluating
-// every face of a tile for all the tile's pixels does 4.6x more lane evaluations; one global atomic per
-// candidate is capped at ~50 G/s (memory-side on this multi-XCD part, 0.7 ms per sweep); per-pixel candidate
-// lists in HBM mean 35-50 M scattered 8-byte stores.  Hence:
-//   face_bbox  per-face pixel box + a packed record (box, 3 screen-space vertices), and the union box of every
-//              32 consecutive faces.  Faces are Morton-ordered once at model creation, so consecutive faces are
-//              screen-space neighbours in any pose.
-//   sweep      one block per 128 consecutive faces: candidates are accumulated in a 64x64-pixel LDS window
-//              anchored at the block's union box as ONE packed 64-bit integer per pixel
-//              (count << 50 | sum of -log2(1 - p) in 2^-24 fixed point) and flushed with one global atomic
-//              per touched pixel (10-27x fewer than one per candidate).  Integer adds commute: the result does
-//              not depend on arrival order (deterministic).
-//   resolve    thread per pixel: alpha = 2^-sum.  Pixels with more than K candidates get one wave each: it
-//              walks the 32-face union boxes containing the pixel, evaluates those faces (lane per face),
-//              compacts the candidates into LDS in face order, finds the K-th smallest depth exactly with a
-//              4 x 8-bit radix select on an order-preserving key and multiplies the K nearest (1 - p).
-//              The largest included depth (zthr) is stored so that raster_bwd_kernel truncates identically.
+// Measured on MI355X while designing this (64 frames, 256^2): evaluating every face of a tile for all the tile's
+// pixels does 4.6x more lane evaluations than letting each face walk its own blur-expanded pixel box; one global
+// atomic per candidate is capped at ~50 G/s (memory-side on this multi-XCD part); per-pixel candidate lists in HBM
+// mean 35-50 M scattered 8-byte stores.  Hence:
+//   face_bbox  per-face pixel box + a packed 48-byte record (box, 3 screen-space vertices), the union box of every
+//              8 consecutive faces, the frame's reference depth and active pixel region.  Faces are Morton-ordered
+//              once at model creation, so consecutive faces are screen-space neighbours in any pose.
+//   sweep      block = 32 consecutive faces, 16 lanes per face walking the box row-major.  Per pixel two cached
+//              depth bounds lo <= hi: candidates <= lo go into ONE packed 64-bit integer per pixel
+//              (count << 50 | sum of -log2(1 - p) in 2^-24 fixed point; 32x32-pixel LDS window, one global atomic per
+//              touched pixel), candidates in (lo, hi] into the pixel's band list (<= 64 entries, staged per wave),
+//              candidates beyond hi are dropped unevaluated.  Integer adds commute: order-independent results.
+//   resolve    thread per pixel of the active region: with c = #{<= lo}, b = #band the K nearest are proved from
+//              counts (c <= K <= c + b) or the pixel is queued.
+//   band       half-wave per pixel: ranks the band entries, adds the K - c nearest, re-centres / narrows the bounds.
+//   select     wave per queued pixel: exact K nearest from scratch (union boxes -> face boxes -> evaluation ->
+//              candidates in LDS in face order -> K-th depth by linear-histogram refinement + exact ranks), new
+//              bounds sized to the current miss rate.  The cache is only ever a verified shortcut.
+//   bwd        face-parallel gather with the same box walk; the depth of the farthest included candidate is stored
+//              with the adjoint seed so that it applies exactly the forward's truncation.
 // ------------------------------------------------------------------------------------------------
 constexpr int kRectFaces = 8;             // faces per entry of the union-box index
 #ifndef SMALFIT_SWEEP_FACES
