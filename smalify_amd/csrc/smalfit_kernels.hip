@@ -1019,8 +1019,9 @@ raster_resolve_kernel(int S, int M, int window, float w_sil, unsigned long long*
   }
 }
 
-// 5c': band.  Persistent grid, one half-wave per queued pixel, lane per band entry (one coalesced 256-byte read):
-// rank by counting against an LDS broadcast of the 32 depths, include the K - c nearest, check for a tie at the cut.
+// 5c': band.  Persistent grid, one half-wave per queued pixel, two band entries per lane (coalesced 256-byte reads):
+// rank by counting against an LDS broadcast of the depths, include the K - c nearest, check for a tie at the cut,
+// then re-centre (and, when the pose moves little, narrow) the pixel's bounds.
 constexpr int kBandBlocks = 1024;
 __global__ void __launch_bounds__(256)
 raster_band_kernel(int S, int M, int window, float w_sil, unsigned long long* __restrict__ gacc,
@@ -1135,8 +1136,8 @@ raster_band_kernel(int S, int M, int window, float w_sil, unsigned long long* __
 
 // 5d: select.  Persistent grid; one wave per queued pixel: it walks the union boxes (8 faces each)
 // containing the pixel, evaluates those faces (lane per face, record loads software-prefetched), compacts
-// the candidates into LDS in face order, finds the K-th smallest depth exactly (4 x 8-bit radix select on an
-// order-preserving key) and multiplies the K nearest (1 - p) in a fixed order.
+// the candidates into LDS in face order, finds the K-th smallest depth exactly (histogram over a linear quantisation
+// of the depth range, narrowed to <= 64 entries, then exact ranks) and multiplies the K nearest (1 - p) in a fixed order.
 constexpr int kCandCap = 1024;            // candidates per pixel kept in LDS; beyond: multi-pass re-evaluation
 constexpr int kHitCap = 1024;             // union boxes containing a pixel kept in LDS (aliases the candidate buffer)
 constexpr int kCoverCap = 2048;           // faces whose box covers the pixel, kept in LDS (u16 ids)
@@ -1580,8 +1581,8 @@ __global__ void gpix_from_dsil_kernel(size_t total, const float* __restrict__ si
   if (i < total) gz[i].x = -dsil[i] * (1.0f - sil[i]) * (1.0f / kSigma);
 }
 
-// 5d: backward, face-parallel gather (deterministic, no atomics).  16 lanes per face sweep the face's
-// pixel box in 4x4 patches; d(signed dist^2)/d(vertex) flows through the nearest edge only.
+// 5e: backward, face-parallel gather (deterministic, no atomics).  16 lanes per face walk the face's pixel box
+// row-major like the forward sweep; d(signed dist^2)/d(vertex) flows through the nearest edge only.
 __global__ void __launch_bounds__(256)
 raster_bwd_kernel(int F, int S, const float4* __restrict__ frec, const float* __restrict__ zc, const float2* __restrict__ gz,
                   float* __restrict__ dface /*[M][F][6]*/) {
