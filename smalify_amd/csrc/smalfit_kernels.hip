@@ -1043,19 +1043,37 @@ raster_band_kernel(int S, int M, int window, float w_sil, unsigned long long* __
   // change while this kernel runs, so the decision is the same in every run)
   const float miss = (float)qcount[2] / (float)max(qcount[2] + nb, 1);
   const int fill_target = (miss > 0.12f) ? kBandFillWide : ((miss > 0.02f) ? kBandFill : kBandFillNarrow);
+  // Software pipeline over this half-wave's pixels: the operands of pixel j + 1 (five loads that depend on its queue
+  // entry) are in flight while pixel j is ranked; the queue entry itself is fetched two pixels ahead.
   const int jstep = gridDim.x * 8;
-  int gp_next = (blockIdx.x * 8 + hw < nb) ? bqueue[blockIdx.x * 8 + hw] : 0;
-  for (int j = blockIdx.x * 8 + hw; j < nb; j += jstep) {
-    const int gp = gp_next;
-    if (j + jstep < nb) gp_next = bqueue[j + jstep];    // next pixel's id in flight during this one
+  const int j0 = blockIdx.x * 8 + hw;
+  struct Operands { int gp; unsigned long long vb; int b; float ts; float2 zb, v, u; };
+  auto fetch = [&](int gp) {
+    Operands o;
+    o.gp = gp;
     const size_t pi = (size_t)gp;
-    // everything this pixel needs in one round trip (list slots are read whether or not they are occupied); a lane
-    // holds entries hl and hl + 32 -- the second half only exists for wide bands (large parameter steps)
-    const unsigned long long vb = gacc[pi];
-    const int b = (int)bcnt[pi];
-    const float ts = tsil ? tsil[pi] : 0.f;
-    const float2 zb_old = zband[pi];
-    float2 v = blist[pi * kBandCap + hl], u = blist[pi * kBandCap + 32 + hl];
+    o.vb = gacc[pi];
+    o.b = (int)bcnt[pi];
+    o.ts = tsil ? tsil[pi] : 0.f;
+    o.zb = zband[pi];
+    o.v = blist[pi * kBandCap + hl];                      // list slots are read whether or not they are occupied
+    o.u = blist[pi * kBandCap + 32 + hl];
+    return o;
+  };
+  Operands nxt = fetch((j0 < nb) ? bqueue[j0] : 0);
+  int gp_after = (j0 + jstep < nb) ? bqueue[j0 + jstep] : 0;
+  for (int j = j0; j < nb; j += jstep) {
+    const Operands cur = nxt;
+    if (j + jstep < nb) nxt = fetch(gp_after);
+    if (j + 2 * jstep < nb) gp_after = bqueue[j + 2 * jstep];
+    const int gp = cur.gp;
+    const size_t pi = (size_t)gp;
+    // a lane holds entries hl and hl + 32 -- the second half only exists for wide bands (large parameter steps)
+    const unsigned long long vb = cur.vb;
+    const int b = cur.b;
+    const float ts = cur.ts;
+    const float2 zb_old = cur.zb;
+    float2 v = cur.v, u = cur.u;
     if (hl >= b) v = make_float2(kInf, 0.f);
     if (hl + 32 >= b) u = make_float2(kInf, 0.f);
     const bool wide = b > 32;                              // uniform over the half-wave
