@@ -56,8 +56,9 @@ class ShardedFitter:
 
     def _set_halos(self, records):
         f = self.fitter
-        f.halo_prev = records[self.rank - 1, 1].contiguous() if self.rank > 0 else None
-        f.halo_next = records[self.rank + 1, 0].contiguous() if self.rank + 1 < self.world else None
+        # rows of the gathered buffer are contiguous: views, no copies
+        f.halo_prev = records[self.rank - 1, 1] if self.rank > 0 else None
+        f.halo_next = records[self.rank + 1, 0] if self.rank + 1 < self.world else None
         self._halo_valid = True
 
     def exchange_halos(self):
@@ -84,20 +85,27 @@ class ShardedFitter:
             f.apply_adam(local, lr)
             first = False
         sg = f.shared_grad()
-        rec = f.boundary_records().reshape(-1)
-        payload = torch.cat([sg, rec.to(sg.dtype)])
-        if self._gather is None or self._gather.numel() != self.world * payload.numel() or self._gather.dtype != payload.dtype:
-            self._gather = torch.empty(self.world * payload.numel(), device=payload.device, dtype=payload.dtype)
-        dist.all_gather_into_tensor(self._gather, payload, group=self.group)
-        g = self._gather.view(self.world, payload.numel())
+        ns = sg.numel()
+        if self._gather is None or self._gather.numel() != self.world * (ns + 216) or self._gather.dtype != sg.dtype:
+            self._payload = torch.empty(ns + 216, device=sg.device, dtype=sg.dtype)
+            self._gather = torch.empty(self.world * (ns + 216), device=sg.device, dtype=sg.dtype)
+        self._payload[:ns].copy_(sg)
+        self._fill_boundary(self._payload[ns:])
+        dist.all_gather_into_tensor(self._gather, self._payload, group=self.group)
+        g = self._gather.view(self.world, ns + 216)
         if shared:
-            total = g[0, : sg.numel()].clone()
-            for r in range(1, self.world):                     # rank order: same bits on every rank
-                total += g[r, : sg.numel()]
-            sg.copy_(total)
+            # one reduction kernel over the ranks; every rank runs the same kernel on the same bytes: identical results
+            torch.sum(g[:, :ns], dim=0, out=sg)
             f.apply_adam(shared, lr, advance=first)
-        self._set_halos(g[:, sg.numel():].reshape(self.world, 2, 108).to(rec.dtype))
+        self._set_halos(g[:, ns:].view(self.world, 2, 108))
         return f.losses
+
+    def _fill_boundary(self, out):
+        f = self.fitter
+        try:
+            f.boundary_records(out=out)
+        except TypeError:                                   # fitters without the `out` fast path
+            out.copy_(f.boundary_records().reshape(-1).to(out.dtype))
 
     def global_losses(self):
         """sum of the per-rank loss terms (reporting only)"""

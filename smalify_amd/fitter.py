@@ -146,12 +146,24 @@ class FusedFitter:
         """view of the gradient of the parameters every frame shares (betas, and the limb scales when shared)"""
         return self.grad[: 20 + (6 if self.ls_shared else 0)]
 
-    def boundary_records(self):
-        """(2,108) masked theta(105)|trans(3) of the first and the last local frame (temporal halo exchange)"""
-        idx = [0, self.N - 1]
-        gr = self.p["global_rotation"][idx] * self.global_mask
-        jr = (self.p["joint_rotations"][idx] * self.rotation_mask).reshape(2, 102)
-        return torch.cat([gr, jr, self.p["trans"][idx]], 1).contiguous()
+    def boundary_records(self, out=None):
+        """(2,108) masked theta(105)|trans(3) of the first and the last local frame (temporal halo exchange): one
+        gather from the flat parameter buffer and one multiply with the masks; `out` (216 floats) avoids allocations"""
+        if getattr(self, "_brec_index", None) is None:
+            idx, msk = [], []
+            for n in (0, self.N - 1):
+                o_g, o_j, o_t = self.offsets["global_rotation"][0], self.offsets["joint_rotations"][0], self.offsets["trans"][0]
+                idx += [o_g + n * 3 + k for k in range(3)] + [o_j + n * 102 + k for k in range(102)] + [o_t + n * 3 + k for k in range(3)]
+            self._brec_index = torch.tensor(idx, device=self.flat.device, dtype=torch.long)
+        key = (id(self.global_mask), self.global_mask._version, id(self.rotation_mask), self.rotation_mask._version)
+        if getattr(self, "_brec_mask_key", None) != key:
+            m = torch.cat([self.global_mask.reshape(-1), self.rotation_mask.reshape(-1), torch.ones(3, device=self.flat.device)])
+            self._brec_mask, self._brec_mask_key = torch.cat([m, m]), key
+        rec = torch.index_select(self.flat, 0, self._brec_index)
+        if out is None:
+            return (rec * self._brec_mask).view(2, 108)
+        torch.mul(rec, self._brec_mask, out=out)
+        return out.view(2, 108)
 
     def run_schedule(self, opt_weights=None, iters_scale=1.0, on_visualize=None, vis_frequency=None):
         """The reference's full stage loop. Returns per-stage final loss vectors (host)."""

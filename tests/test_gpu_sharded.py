@@ -1,0 +1,99 @@
+"""GPU test of the frame-sharded loop: two processes on one GPU (gloo moves the 1 KB records), each with a FusedFitter on
+half of the frames, against one process fitting all of them.  The collective itself is not the point here (RCCL is
+exercised by bench.py --gpus N on a multi-GPU node); the point is that ShardedFitter + the HIP engine with halo frames
+reproduce the unsharded fit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_FRAMES, SIZE, WINDOW = 8, 64, 4
+SCHEDULE = ((0, 3), (1, 3), (2, 4))
+
+
+def _setup():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity_cases as pc
+    _, prob, cur, tg = pc.make_problem(N_FRAMES, SIZE, WINDOW, 21)
+    return pc, cur, tg
+
+
+def _run(fitter_factory, rank, world):
+    from smalify_amd import config as cfg, distributed
+    pc, cur, tg = _setup()
+    lo, hi = distributed.shard_range(N_FRAMES, rank, world, window=WINDOW)
+    f = fitter_factory(pc, cur, tg, lo, hi)
+    sf = distributed.ShardedFitter(f, rank, world) if world > 1 else f
+    W = np.array(cfg.OPT_WEIGHTS).T
+    for stage_id, its in SCHEDULE:
+        sf.begin_stage(stage_id)
+        for _ in range(its):
+            sf.step(W[stage_id][:6], float(W[stage_id][6]), float(W[stage_id][8]), stage_id)
+    return {k: v.detach().cpu().numpy().copy() for k, v in f.p.items()}
+
+
+def _factory(pc, cur, tg, lo, hi):
+    from smalify_amd import engine as eng, fitter as fit, synthetic
+    _, _, dm = pc.get_model()
+    e = eng.Engine(dm, hi - lo, SIZE)
+    e.set_pose_prior(*synthetic.synthetic_pose_prior())
+    e.set_shape_prior(*synthetic.synthetic_shape_prior())
+    f = fit.FusedFitter(e, tg["tj"][lo:hi], tg["vis"][lo:hi], tg["tsil"][lo:hi], WINDOW, True, cur["betas"], cur["log_beta_scales"])
+    for k in ("global_rotation", "joint_rotations", "trans"):
+        f.p[k].copy_(pc.dev(cur[k][lo:hi]))
+    return f
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank, _run(_factory, rank, world)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_the_unsharded_fit():
+    single = _run(_factory, 0, 1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        import queue as _queue
+        for _ in range(600):
+            try:
+                r, val = q.get(timeout=1.0)
+                got[r] = val
+                if len(got) == 2:
+                    break
+            except _queue.Empty:
+                if any(p.exitcode not in (None, 0) for p in procs):
+                    break
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert len(got) == 2, "a rank died: exit codes %s" % [p.exitcode for p in procs]
+    half = N_FRAMES // 2
+    for k in ("global_rotation", "joint_rotations", "trans"):
+        both = np.concatenate([got[0][k], got[1][k]], 0)
+        err = np.linalg.norm(both - single[k]) / np.linalg.norm(single[k])
+        assert err < 2e-5, (k, err)
+    for k in ("betas", "log_beta_scales"):
+        assert np.array_equal(got[0][k], got[1][k]), k            # shared parameters: identical bits on both ranks
+        err = np.linalg.norm(got[0][k] - single[k]) / np.linalg.norm(single[k])
+        assert err < 2e-5, (k, err)
