@@ -1156,9 +1156,15 @@ raster_band_kernel(int S, int M, int window, float w_sil, unsigned long long* __
 // containing the pixel, evaluates those faces (lane per face, record loads software-prefetched), compacts
 // the candidates into LDS in face order, finds the K-th smallest depth exactly (histogram over a linear quantisation
 // of the depth range, narrowed to <= 64 entries, then exact ranks) and multiplies the K nearest (1 - p) in a fixed order.
-constexpr int kCandCap = 1024;            // candidates per pixel kept in LDS; beyond: multi-pass re-evaluation
-constexpr int kHitCap = 1024;             // union boxes containing a pixel kept in LDS (aliases the candidate buffer)
-constexpr int kCoverCap = 2048;           // faces whose box covers the pixel, kept in LDS (u16 ids)
+#ifndef SMALFIT_CAND_CAP
+#define SMALFIT_CAND_CAP 1024
+#endif
+#ifndef SMALFIT_COVER_CAP
+#define SMALFIT_COVER_CAP 2048
+#endif
+constexpr int kCandCap = SMALFIT_CAND_CAP;   // candidates per pixel kept in LDS; beyond: multi-pass re-evaluation
+constexpr int kHitCap = 2 * SMALFIT_CAND_CAP < 1024 ? 2 * SMALFIT_CAND_CAP : 1024;   // union boxes containing a pixel kept in LDS (aliases the candidate buffer)
+constexpr int kCoverCap = SMALFIT_COVER_CAP;   // faces whose box covers the pixel, kept in LDS (u16 ids)
 
 constexpr int kSelWaves = 2;              // waves per select block: 13 KB of LDS per wave -> 6 blocks (12 waves) per CU
 

