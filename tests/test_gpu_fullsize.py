@@ -125,6 +125,19 @@ def test_renderer_thousands_of_candidates_per_pixel():
     assert m["render_dverts_rel"] < 5e-2, m
 
 
+@pytest.mark.parametrize("z", [2.55, 2.7, 3.5])
+def test_renderer_mesh_at_and_behind_the_camera_plane(z):
+    """translation z = 2.55 / 2.7 puts part of / half of the animal behind the camera plane (view depth <= 0: projected
+    coordinates blow up and change sign, faces are kept while any vertex has depth >= 0, pixels need pz >= 0);
+    z = 3.5 puts all of it behind (every face culled)"""
+    m = pc.case_render(1, 64, z, 41)
+    assert m["render_status"] == 0
+    assert m["sil_maxabs"] < 2e-3, m
+    assert m["sil_frac_gt_1e-4"] < 1e-2, m
+    if z == 3.5:
+        assert m["render_coverage"] == 0.0
+
+
 def test_renderer_mesh_off_screen():
     """no face box on screen: empty active region, silhouette exactly 0, zero vertex gradient"""
     md, om, _ = pc.get_model()
