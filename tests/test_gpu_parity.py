@@ -33,9 +33,10 @@ def test_adam():
     assert pc.case_adam()["adam_rel"] < 1e-6
 
 
-@pytest.mark.parametrize("M,dense,with_scale", [(3, False, True), (3, True, False), (8, False, True), (21, False, True)])
+@pytest.mark.parametrize("M,dense,with_scale", [(3, False, True), (3, True, False), (8, False, True), (8, True, False), (21, False, True)])
 def test_lbs_forward_backward(M, dense, with_scale):
-    """M = 8 and 21 take the matrix-core pose-blend kernel (frames in tiles of 16: a half-empty tile, a ragged second tile)"""
+    """M = 8 and 21 take the matrix-core pose-blend kernel (frames in tiles of 16: a half-empty tile, a ragged second tile);
+    dense = the reference's dense (V,35) weight matrices, i.e. 35 skinning weights per vertex"""
     m = pc.case_lbs(M, dense, with_scale)
     for k in ("lbs_verts_rel", "lbs_joints_rel", "lbs_Rs_rel", "lbs_vshaped_rel"):
         assert m[k] < 2e-5, (k, m[k])
