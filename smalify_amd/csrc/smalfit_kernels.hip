@@ -8,6 +8,10 @@
 //   matrices of the reference (smal_torch.py:78-96) are mostly zeros; a dense matrix is simply an ELL
 //   with 35 entries per row, the code path is the same and the sums run in the same joint order.
 //
+// One translation unit: this file holds the shared device helpers and includes the kernels by subsystem
+// (kernels_lbs_forward.inc, kernels_raster.inc, kernels_color.inc, kernels_lbs_backward.inc), then the host side
+// (smalfit_launch.inc).
+//
 // Kernel -> reference map (file:line into /root/reference):
 //   lbs_head_kernel     pose blocks: batch_lbs.py:33-52 (Rodrigues), :105-129 (limb scales), :131-168 (chain, A);
 //                       shape blocks: smal_torch.py:115 (+ :125-128 through the precomputed J0 + JS beta);
@@ -84,2356 +88,10 @@ __device__ __forceinline__ int frame_window_size(int n, int M, int window) {
   return rem < window ? rem : window;
 }
 
-// ------------------------------------------------------------------------------------------------
-// K0: shape blend + rest joints
-// ------------------------------------------------------------------------------------------------
-
-// ------------------------------------------------------------------------------------------------
-// K1: per-frame pose: Rodrigues, limb scales, kinematic chain, skinning transforms, pose feature
-// ------------------------------------------------------------------------------------------------
-// K0+K1a in one launch: per-frame pose blocks (masked axis-angles -> Rodrigues -> limb scales -> kinematic chain by
-// tree depth -> A_j and the pose feature; the rest joints J = Jt + JS beta are formed in place), the shape-blend
-// blocks (v_shaped = v_template + shapedirs beta) and, for the fitter, the shape-prior block.  The three parts are
-// independent and each is latency-bound: one launch instead of four.
-struct HeadArgs {
-  int M, Mp, nb, betas_stride, ls_stride, nshape_x, nshape, prior_D, prior_use_ls;
-  const float* betas;        // [nbs][betas_stride]
-  const float* theta_in;     // [M][105] ready-made (component API) or null
-  const float* grot;         // [M][3], jrot [M][102], masks: used when theta_in is null
-  const float* jrot;
-  const float* gmask;
-  const float* rmask;
-  const float* logscale;     // [.][6] or null
-  float* theta;              // [M][105] out (masked axis-angles)
-  float* Jrest;              // [nbs][105] out
-  float* v_shaped;           // [nbs][3][Vp] out
-  float *Rm, *Gm, *scm, *Am, *pfT;
-  const float* prior_prec;   // shape prior (null: none)
-  const float* prior_mean;
-  float prior_w;
-  float *prior_loss, *prior_gb, *prior_gls;
-};
-
-__device__ __forceinline__ void
-pose_block(const ModelDev& m, const HeadArgs& a, int n) {
-  __shared__ float th[105];
-  __shared__ float R[35][9];
-  __shared__ float sc[35][3], isc[35][3];
-  __shared__ float G[35][12];
-  __shared__ float J[35][3];
-  __shared__ unsigned char t_lvl_off[36], t_lvl_joint[36], t_par[36];
-  const int l = threadIdx.x, M = a.M;
-  const TreeLevels& tl = m.tree;
-  if (l < 36) {
-    t_lvl_off[l] = tl.lvl_off[l];
-    if (l < 35) { t_lvl_joint[l] = tl.lvl_joint[l]; t_par[l] = (unsigned char)max(m.parents[l], 0); }
-  }
-  const int nlev = tl.nlev;
-  if (l < 105) {
-    float tv;
-    if (a.theta_in) tv = a.theta_in[(size_t)n * 105 + l];
-    else tv = (l < 3) ? a.grot[n * 3 + l] * a.gmask[l] : a.jrot[(size_t)n * 102 + (l - 3)] * a.rmask[l - 3];
-    th[l] = tv;
-    a.theta[(size_t)n * 105 + l] = tv;
-    // rest joint coordinate l of this frame's shape
-    const float* beta = a.betas + (size_t)(a.betas_stride ? n : 0) * a.betas_stride;
-    float acc = m.Jt[l];
-    for (int b = 0; b < a.nb; ++b) acc = fmaf(m.JS[l * m.NBall + b], beta[b], acc);
-    J[l / 3][l % 3] = acc;
-    if (a.betas_stride || n == 0) a.Jrest[(size_t)(a.betas_stride ? n : 0) * 105 + l] = acc;
-    const int idx = m.scale_idx[l];
-    const float sv = (a.logscale != nullptr && idx >= 0) ? expf(a.logscale[(size_t)n * a.ls_stride + idx]) : 1.0f;
-    sc[l / 3][l % 3] = sv; isc[l / 3][l % 3] = 1.0f / sv;
-    a.scm[(size_t)n * 105 + l] = sv;
-  }
-  __syncthreads();
-  if (l < 35) {
-    const float t3[3] = {th[l * 3], th[l * 3 + 1], th[l * 3 + 2]};
-    float r[9];
-    rodrigues_fwd(t3, r);
-#pragma unroll
-    for (int e = 0; e < 9; ++e) { R[l][e] = r[e]; a.Rm[((size_t)n * 35 + l) * 9 + e] = r[e]; }
-  }
-  __syncthreads();
-  for (int idx = l; idx < 306; idx += 256) {
-    const int j = idx / 9 + 1, e = idx % 9;
-    a.pfT[(size_t)idx * a.Mp + n] = R[j][e] - ((e & 3) == 0 ? 1.0f : 0.0f);
-  }
-  if (l < 12) {
-    const int r = l >> 2, c = l & 3;
-    G[0][l] = (c < 3) ? R[0][r * 3 + c] : J[0][r];
-  }
-  // the tree by depth: 12 lanes per joint of the level, first wave only (its LDS operations complete in order)
-  if (l < 64) {
-    const int slot = l / 12, e = l % 12;
-    for (int L = 1; L < nlev; ++L) {
-      const int j0 = t_lvl_off[L], nj = t_lvl_off[L + 1] - j0;
-      for (int base = 0; base < nj; base += 5) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        if (slot < 5 && base + slot < nj) {
-          const int i = t_lvl_joint[j0 + base + slot], p = t_par[i];
-          const int r = e >> 2, c = e & 3;
-          float acc;
-          if (c < 3) {
-            acc = 0.f;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) acc = fmaf(G[p][r * 4 + q], R[i][q * 3 + c] * sc[i][c] * isc[p][q], acc);
-          } else {
-            acc = G[p][r * 4 + 3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) acc = fmaf(G[p][r * 4 + q], J[i][q] - J[p][q], acc);
-          }
-          G[i][e] = acc;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  for (int idx = l; idx < 35 * 12; idx += 256) {
-    const int j = idx / 12, e = idx % 12, r = e >> 2, c = e & 3;
-    float val = G[j][e];
-    if (c == 3) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q) val = fmaf(-G[j][r * 4 + q], J[j][q], val);
-    }
-    a.Am[(size_t)n * 420 + idx] = val;
-    a.Gm[(size_t)n * 420 + idx] = G[j][e];
-  }
-  (void)M;
-}
-
-__global__ void __launch_bounds__(256)
-lbs_head_kernel(ModelDev m, HeadArgs a) {
-  int blk = blockIdx.x;
-  if (blk < a.M) { pose_block(m, a, blk); return; }
-  blk -= a.M;
-  if (blk < a.nshape) {
-    const int s = blk / a.nshape_x;
-    const float* beta = a.betas + (size_t)s * a.betas_stride;
-    const int v = (blk % a.nshape_x) * 256 + threadIdx.x;
-    const int Vp = m.Vp;
-    if (v < Vp) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float acc = m.vt[c * Vp + v];
-        for (int b = 0; b < a.nb; ++b) acc = fmaf(beta[b], m.sd[((size_t)b * 3 + c) * Vp + v], acc);
-        a.v_shaped[((size_t)s * 3 + c) * Vp + v] = acc;
-      }
-    }
-    return;
-  }
-  // shape prior: w_eff * mean_c( ((x - mean) prec)_c ^2 ), x = [betas | log scales]
-  if (a.prior_prec && threadIdx.x < 64) {
-    __shared__ float x[32], res[32];
-    const int t = threadIdx.x, D = a.prior_D;
-    if (t < D) x[t] = ((t < 20) ? a.betas[t] : a.logscale[t - 20]) - a.prior_mean[t];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    float lv = 0.f;
-    if (t < D) {
-      float acc = 0.f;
-      for (int r = 0; r < D; ++r) acc = fmaf(x[r], a.prior_prec[r * D + t], acc);
-      res[t] = acc;
-      lv = acc * acc;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    lv = wave_sum(lv);
-    if (t == 0) *a.prior_loss = a.prior_w * lv / (float)D;
-    if (t < D) {
-      float acc = 0.f;
-      for (int c = 0; c < D; ++c) acc = fmaf(res[c], a.prior_prec[t * D + c], acc);
-      acc *= 2.0f * a.prior_w / (float)D;
-      if (t < 20) a.prior_gb[t] = acc; else if (a.prior_use_ls) a.prior_gls[t - 20] = acc;
-    }
-  }
-}
-
-// theta[n][0] = global_rotation[n] * gmask ; theta[n][1+j] = joint_rotations[n][j] * rmask[j]
-__global__ void build_theta_kernel(int M, const float* __restrict__ grot, const float* __restrict__ jrot,
-                                   const float* __restrict__ gmask, const float* __restrict__ rmask,
-                                   float* __restrict__ theta) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= M * 105) return;
-  const int n = i / 105, e = i % 105;
-  theta[i] = (e < 3) ? grot[n * 3 + e] * gmask[e] : jrot[n * 102 + (e - 3)] * rmask[e - 3];
-}
-
-// ------------------------------------------------------------------------------------------------
-// K2: pose blend + skinning + camera transform.  block = 64 vertices x FR frames, 4 waves split K=306
-// ------------------------------------------------------------------------------------------------
-// K1b (MFMA form): pose blend as a skinny GEMM on the matrix cores, then skinning + camera.
-//   blend[n][c] = sum_k pf[n][k] * pd[k][c]   (n: 16 frames, c: 16 vertices x {x,y,z}, k: 306 pose features)
-// One wave owns 16 vertices x 16 frames; v_mfma_f32_16x16x4_f32 (exact f32: an fmaf chain) takes
-// A[i = lane & 15][k = lane >> 4] = pfT[k][n0 + i] and B[k = lane >> 4][j = lane & 15] = pd[k][a][v0 + j], both read
-// straight from global memory as 64-byte segments; D[row = 4 (lane >> 4) + r][col = lane & 15], so a lane ends up with
-// x, y, z of ONE vertex for FOUR frames -- exactly what the skinning step needs.  77 k-steps x 3 MFMAs per wave.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-__global__ void __launch_bounds__(256)
-skin_mfma_kernel(ModelDev m, int M, int Mp, const float* __restrict__ v_shaped, int vs_stride /*0 | 3*Vp*/,
-                 const float* __restrict__ pfT, const float* __restrict__ Am, const float* __restrict__ trans,
-                 float* __restrict__ vposed, float* __restrict__ verts, float* __restrict__ proj) {
-  __shared__ float As[16][420];
-  const int Vp = m.Vp;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int n0 = blockIdx.y * 16;
-  const int v = blockIdx.x * 64 + w * 16 + (lane & 15);
-  const int kq = lane >> 4;
-  for (int i = threadIdx.x; i < 16 * 420; i += 256) {
-    const int f = i / 420;
-    As[f][i % 420] = (n0 + f < M) ? Am[(size_t)(n0 + f) * 420 + (i % 420)] : 0.f;
-  }
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
-  const float* pa = pfT + (size_t)kq * Mp + n0 + (lane & 15);
-  const float* pb = m.pd + (size_t)kq * 3 * Vp + v;
-  // 77 k-steps of 4 pose features (features 306, 307 do not exist: pfT has two zero rows there and the pd row is
-  // clamped, 0 * finite = 0).  With about one wave per SIMD nothing hides a load but the wave itself: operands are
-  // fetched a batch of 11 steps ahead (44 loads in flight) into two register sets used alternately.
-  constexpr int U = 11, NBATCH = 7;
-  static_assert(U * NBATCH == 77, "306 pose features in steps of 4");
-  float xa[U], x0[U], x1[U], x2[U], ya[U], y0[U], y1[U], y2[U];
-  auto load_batch = [&](int bt, float* A, float* B0, float* B1, float* B2) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int st = bt * U + u;
-      A[u] = pa[(size_t)st * 4 * Mp];
-      const float* b = pb + (size_t)(min(st * 4 + kq, 305) - kq) * 3 * Vp;
-      B0[u] = b[0]; B1[u] = b[Vp]; B2[u] = b[2 * Vp];
-    }
-  };
-  auto mfma_batch = [&](const float* A, const float* B0, const float* B1, const float* B2) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u], B0[u], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u], B1[u], acc1, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u], B2[u], acc2, 0, 0, 0);
-    }
-  };
-  load_batch(0, xa, x0, x1, x2);
-  for (int bt = 0; bt < NBATCH - 1; bt += 2) {
-    load_batch(bt + 1, ya, y0, y1, y2);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_batch(xa, x0, x1, x2);
-    __builtin_amdgcn_sched_barrier(0);
-    load_batch(bt + 2, xa, x0, x1, x2);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_batch(ya, y0, y1, y2);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  mfma_batch(xa, x0, x1, x2);
-  __syncthreads();
-  // skinning weights of this lane's vertex (ELL), then its four frames
-  int wj[8];
-  float wv[8];
-  const int Kw = min(m.Kw, 8);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    wj[e] = (e < Kw) ? m.w_j[e * Vp + v] : 0;
-    wv[e] = (e < Kw) ? m.w_val[e * Vp + v] : 0.f;
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int f = 4 * kq + r, n = n0 + f;
-    if (n >= M) break;
-    const float* vs = v_shaped + (size_t)n * vs_stride;
-    const float vp[3] = {vs[v] + acc0[r], vs[Vp + v] + acc1[r], vs[2 * Vp + v] + acc2[r]};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) vposed[((size_t)n * 3 + a) * Vp + v] = vp[a];
-    float T[12];
-#pragma unroll
-    for (int e = 0; e < 12; ++e) T[e] = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      if (e < Kw) {
-        const float* A = &As[f][wj[e] * 12];
-#pragma unroll
-        for (int c = 0; c < 12; ++c) T[c] = fmaf(wv[e], A[c], T[c]);
-      }
-    }
-    for (int e = 8; e < m.Kw; ++e) {            // models with more than 8 weights per vertex
-      const int j = m.w_j[e * Vp + v];
-      const float wx = m.w_val[e * Vp + v];
-      const float* A = &As[f][j * 12];
-#pragma unroll
-      for (int c = 0; c < 12; ++c) T[c] = fmaf(wx, A[c], T[c]);
-    }
-    float o[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      o[a] = fmaf(T[a * 4], vp[0], fmaf(T[a * 4 + 1], vp[1], fmaf(T[a * 4 + 2], vp[2], T[a * 4 + 3])));
-      verts[((size_t)n * 3 + a) * Vp + v] = o[a];
-    }
-    float xn, yn, zv;
-    world_to_ndc(o[0] + trans[n * 3], o[1] + trans[n * 3 + 1], o[2] + trans[n * 3 + 2], xn, yn, zv);
-    proj[((size_t)n * 3 + 0) * Vp + v] = xn;
-    proj[((size_t)n * 3 + 1) * Vp + v] = yn;
-    proj[((size_t)n * 3 + 2) * Vp + v] = zv;
-  }
-}
-
-template <int FR>
-__global__ void __launch_bounds__(256)
-skin_kernel(ModelDev m, int M, int Mp, const float* __restrict__ v_shaped, int vs_stride /*0 | 3*Vp*/,
-            const float* __restrict__ pfT, const float* __restrict__ Am, const float* __restrict__ trans,
-            float* __restrict__ vposed, float* __restrict__ verts, float* __restrict__ proj) {
-  __shared__ float red[4][FR * 3][64];
-  __shared__ float As[FR][420];
-  const int Vp = m.Vp;
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int v = blockIdx.x * 64 + lane;
-  const int n0 = blockIdx.y * FR;
-  for (int i = threadIdx.x; i < FR * 420; i += 256) {
-    const int f = i / 420;
-    As[f][i % 420] = (n0 + f < M) ? Am[(size_t)(n0 + f) * 420 + (i % 420)] : 0.f;
-  }
-  float acc[FR][3];
-#pragma unroll
-  for (int f = 0; f < FR; ++f) acc[f][0] = acc[f][1] = acc[f][2] = 0.f;
-  const int k0 = (w * 306) / 4, k1 = ((w + 1) * 306) / 4;
-  for (int k = k0; k < k1; ++k) {
-    const float p0 = m.pd[((size_t)k * 3 + 0) * Vp + v];
-    const float p1 = m.pd[((size_t)k * 3 + 1) * Vp + v];
-    const float p2 = m.pd[((size_t)k * 3 + 2) * Vp + v];
-    const float* pf = pfT + (size_t)k * Mp + n0;     // wave-uniform -> scalar loads
-#pragma unroll
-    for (int f = 0; f < FR; ++f) {
-      const float c = pf[f];
-      acc[f][0] = fmaf(c, p0, acc[f][0]);
-      acc[f][1] = fmaf(c, p1, acc[f][1]);
-      acc[f][2] = fmaf(c, p2, acc[f][2]);
-    }
-  }
-#pragma unroll
-  for (int f = 0; f < FR; ++f) {
-    red[w][f * 3 + 0][lane] = acc[f][0];
-    red[w][f * 3 + 1][lane] = acc[f][1];
-    red[w][f * 3 + 2][lane] = acc[f][2];
-  }
-  __syncthreads();
-  // phase 2: wave w finishes frames f = w, w+4, ...
-  for (int f = w; f < FR; f += 4) {
-    const int n = n0 + f;
-    if (n >= M) break;
-    const float* vs = v_shaped + (size_t)n * vs_stride;
-    float vp[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      vp[a] = vs[a * Vp + v] + ((red[0][f * 3 + a][lane] + red[1][f * 3 + a][lane]) +
-                                (red[2][f * 3 + a][lane] + red[3][f * 3 + a][lane]));
-      vposed[((size_t)n * 3 + a) * Vp + v] = vp[a];
-    }
-    float T[12];
-#pragma unroll
-    for (int e = 0; e < 12; ++e) T[e] = 0.f;
-    for (int e = 0; e < m.Kw; ++e) {
-      const int j = m.w_j[e * Vp + v];
-      const float wv = m.w_val[e * Vp + v];
-      const float* A = &As[f][j * 12];
-#pragma unroll
-      for (int c = 0; c < 12; ++c) T[c] = fmaf(wv, A[c], T[c]);
-    }
-    float o[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      o[a] = fmaf(T[a * 4], vp[0], fmaf(T[a * 4 + 1], vp[1], fmaf(T[a * 4 + 2], vp[2], T[a * 4 + 3])));
-      verts[((size_t)n * 3 + a) * Vp + v] = o[a];
-    }
-    float xn, yn, zv;
-    world_to_ndc(o[0] + trans[n * 3], o[1] + trans[n * 3 + 1], o[2] + trans[n * 3 + 2], xn, yn, zv);
-    proj[((size_t)n * 3 + 0) * Vp + v] = xn;
-    proj[((size_t)n * 3 + 1) * Vp + v] = yn;
-    proj[((size_t)n * 3 + 2) * Vp + v] = zv;
-  }
-}
-
-// camera transform only (Renderer called with externally supplied vertices): vin (M,V,3) interleaved
-__global__ void project_verts_kernel(int M, int V, int Vp, const float* __restrict__ vin,
-                                     float* __restrict__ proj) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
-  if (v >= Vp) return;
-  float xn = 0.f, yn = 0.f, zv = 1.f;
-  if (v < V) {
-    const float* p = vin + ((size_t)n * V + v) * 3;
-    world_to_ndc(p[0], p[1], p[2], xn, yn, zv);
-  }
-  proj[((size_t)n * 3 + 0) * Vp + v] = xn;
-  proj[((size_t)n * 3 + 1) * Vp + v] = yn;
-  proj[((size_t)n * 3 + 2) * Vp + v] = zv;
-}
-
-// planar [n][3][Vp] -> interleaved (M,V,3), optionally + per-frame offset
-__global__ void planar_to_interleaved_kernel(int M, int V, int Vp, const float* __restrict__ src, int src_stride,
-                                             const float* __restrict__ offs, float* __restrict__ dst) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
-  if (i >= V * 3) return;
-  const int v = i / 3, a = i % 3;
-  float val = src[(size_t)n * src_stride + a * Vp + v];
-  if (offs) val += offs[n * 3 + a];
-  dst[(size_t)n * V * 3 + i] = val;
-}
-
-__global__ void interleaved_to_planar_kernel(int M, int V, int Vp, const float* __restrict__ src,
-                                             float* __restrict__ dst) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
-  if (v >= Vp) return;
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-    dst[((size_t)n * 3 + a) * Vp + v] = (v < V) ? src[((size_t)n * V + v) * 3 + a] : 0.f;
-}
-
-// ------------------------------------------------------------------------------------------------
-// K3: posed joints (35 regressed through the sparse regressor + 6 landmark vertices)
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(128)
-joints_kernel(ModelDev m, const float* __restrict__ verts, float* __restrict__ joints /*[M][41][3]*/) {
-  __shared__ float red[16];
-  const int j = blockIdx.x, n = blockIdx.y, Vp = m.Vp;
-  const float* vx = verts + (size_t)n * 3 * Vp;
-  if (j >= 35) {
-    if (threadIdx.x < 3) joints[((size_t)n * 41 + j) * 3 + threadIdx.x] = vx[threadIdx.x * Vp + m.landmarks[j - 35]];
-    return;
-  }
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-  for (int i = m.jr_off[j] + threadIdx.x; i < m.jr_off[j + 1]; i += 128) {
-    const int v = m.jr_v[i];
-    const float c = m.jr_val[i];
-    a0 = fmaf(c, vx[v], a0);
-    a1 = fmaf(c, vx[Vp + v], a1);
-    a2 = fmaf(c, vx[2 * Vp + v], a2);
-  }
-  a0 = block_sum(a0, red);
-  a1 = block_sum(a1, red);
-  a2 = block_sum(a2, red);
-  if (threadIdx.x == 0) {
-    float* o = joints + ((size_t)n * 41 + j) * 3;
-    o[0] = a0; o[1] = a1; o[2] = a2;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K4: per-frame losses with their direct adjoints: keypoints, pose prior, splay, temporal
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(128)
-loss_kernel(LossArgs a) {
-  __shared__ float th[105], x[105], res[105], dth[105];
-  __shared__ float dJ[41 * 3];
-  __shared__ float red[16];
-  const int n = blockIdx.x, t = threadIdx.x;
-  const int Bn = frame_window_size(n, a.M, a.window);
-  for (int i = t; i < 105; i += 128) { th[i] = a.theta[n * 105 + i]; dth[i] = 0.f; }
-  for (int i = t; i < 123; i += 128) dJ[i] = 0.f;
-  __syncthreads();
-  const float tx = a.trans[n * 3], ty = a.trans[n * 3 + 1], tz = a.trans[n * 3 + 2];
-  float l_joint = 0.f, l_pose = 0.f, l_splay = 0.f, l_tj = 0.f, l_tg = 0.f, l_tt = 0.f;
-  // ---- keypoints (smal_fitter.py:129-144, p3d_renderer.py:67-68) --------------------------------
-  if (t < 25) {
-    const int cj = a.canon[t];
-    const float* jp = a.joints + ((size_t)n * 41 + cj) * 3;
-    float xn, yn, zv;
-    world_to_ndc(jp[0] + tx, jp[1] + ty, jp[2] + tz, xn, yn, zv);
-    const float half = 0.5f * (float)(a.S - 1);
-    const float row = half * (1.0f - yn), col = half * (1.0f - xn);
-    if (a.proj_out) { a.proj_out[(n * 25 + t) * 2] = row; a.proj_out[(n * 25 + t) * 2 + 1] = col; }
-    if (a.w_j2d > 0.f && a.vis[n * 25 + t] != 0.f) {
-      const float dr = row - a.tj[(n * 25 + t) * 2], dc = col - a.tj[(n * 25 + t) * 2 + 1];
-      l_joint = dr * dr + dc * dc;
-      const float k = 2.0f * a.w_j2d / (50.0f * (float)Bn);
-      // row = half (1 - yn), col = half (1 - xn)
-      float gx, gy, gz;
-      world_to_ndc_bwd(xn, yn, zv, -half * k * dc, -half * k * dr, gx, gy, gz);
-      atomicAdd(&dJ[cj * 3 + 0], gx);
-      atomicAdd(&dJ[cj * 3 + 1], gy);
-      atomicAdd(&dJ[cj * 3 + 2], gz);
-    }
-  }
-  // ---- pose prior (pose_prior_35.py:117-124) ------------------------------------------------------
-  if (a.w_pose > 0.f) {
-    if (t < 105) x[t] = th[t] - a.pose_mean[t];
-    __syncthreads();
-    if (t < 105) {
-      float acc = 0.f;
-      for (int r = 0; r < 105; ++r) acc = fmaf(x[r], a.pose_prec[r * 105 + t], acc);
-      acc *= a.pose_mask[t];
-      res[t] = acc * a.pose_mask[t];        // d(res^2)/d(pre-mask) = 2 res mask
-      l_pose = acc * acc;
-    }
-    __syncthreads();
-    if (t < 105) {
-      float acc = 0.f;
-      for (int c = 0; c < 105; ++c) acc = fmaf(res[c], a.pose_prec[t * 105 + c], acc);
-      dth[t] += acc * (2.0f * a.w_pose / (105.0f * (float)Bn));
-    }
-  }
-  // ---- splay (smal_fitter.py:159-160) --------------------------------------------------------------
-  if (a.w_splay > 0.f && t >= 3 && t < 105 && ((t % 3) != 1)) {
-    l_splay = th[t] * th[t];
-    dth[t] += 2.0f * a.w_splay * th[t];
-  }
-  // ---- temporal smoothness (smal_fitter.py:177-190); pair (i, i+1) is owned by frame i ------------
-  float dtr = 0.f;
-  if (a.w_temp > 0.f && t < 108) {
-    const bool is_tr = t >= 105;
-    const int e = is_tr ? t - 105 : t;
-    const float D = is_tr ? 3.0f : (e < 3 ? 3.0f : 102.0f);
-    const float cur = is_tr ? a.trans[n * 3 + e] : th[e];
-    float g = 0.f;
-    // next neighbour (owned pair)
-    bool has_next = (n + 1 < a.M) || (a.halo_next != nullptr);
-    if (has_next) {
-      const float nxt = (n + 1 < a.M) ? (is_tr ? a.trans[(n + 1) * 3 + e] : a.theta[(n + 1) * 105 + e])
-                                      : a.halo_next[is_tr ? 105 + e : e];
-      const float d = cur - nxt;
-      const float term = d * d * (a.w_temp / D);
-      if (is_tr) l_tt = term; else if (e < 3) l_tg = term; else l_tj = term;
-      g += d;
-    }
-    bool has_prev = (n > 0) || (a.halo_prev != nullptr);
-    if (has_prev) {
-      const float prv = (n > 0) ? (is_tr ? a.trans[(n - 1) * 3 + e] : a.theta[(n - 1) * 105 + e])
-                                : a.halo_prev[is_tr ? 105 + e : e];
-      g += cur - prv;
-    }
-    g *= 2.0f * a.w_temp / D;
-    if (is_tr) dtr = g; else dth[e] += g;
-  }
-  __syncthreads();
-  // ---- outputs ---------------------------------------------------------------------------------------
-  for (int i = t; i < 105; i += 128) a.dth_direct[n * 105 + i] = dth[i];
-  for (int i = t; i < 123; i += 128) a.dJ41[n * 123 + i] = dJ[i];
-  if (t >= 105 && t < 108) {
-    // d trans: temporal part + sum over the 41 joint adjoints (joints = regress(verts) + trans)
-    float s = dtr;
-    const int e = t - 105;
-    for (int j = 0; j < 41; ++j) s += dJ[j * 3 + e];
-    a.dtr_direct[n * 3 + e] = s;
-  }
-  const float nj = 1.0f / (50.0f * (float)Bn), np_ = 1.0f / (105.0f * (float)Bn);
-  l_joint = block_sum(l_joint, red);
-  l_pose = block_sum(l_pose, red);
-  l_splay = block_sum(l_splay, red);
-  l_tj = block_sum(l_tj, red);
-  l_tg = block_sum(l_tg, red);
-  l_tt = block_sum(l_tt, red);
-  if (t == 0) {
-    float* o = a.loss_part + n * 8;
-    o[0] = a.w_j2d * nj * l_joint;
-    o[1] = a.w_pose * np_ * l_pose;
-    o[2] = a.w_splay * l_splay;
-    o[3] = 0.f;                // betas (prior block of lbs_head_kernel)
-    o[4] = 0.f;                // silhouette (tile partials)
-    o[5] = l_tj; o[6] = l_tg; o[7] = l_tt;
-  }
-}
-
-// shape prior (smal_fitter.py:162-171): loss = w * mean(((b|ls) - mu) P)^2 counted once per window.
-// single block; betas/logscale shared across frames (fitter) -> grads are for the shared vectors.
-
-// ------------------------------------------------------------------------------------------------
-// K5: soft-silhouette rasteriser  (DESIGN.md section 4 has the measurements behind each choice)
-//
-// pytorch3d keeps, per pixel, only the faces_per_pixel = 100 candidates nearest in depth; with the
-// reference's head-on initial pose a pixel sees hundreds of candidates, so the truncation is first-class.
-// Measured on MI355X while designing this (64 frames, 256^2): evaluating every face of a tile for all the tile's
-// pixels does 4.6x more lane evaluations than letting each face walk its own blur-expanded pixel box; one global
-// atomic per candidate is capped at ~50 G/s (memory-side on this multi-XCD part); per-pixel candidate lists in HBM
-// mean 35-50 M scattered 8-byte stores.  Hence:
-//   face_bbox  per-face pixel box + a packed 48-byte record (box, 3 screen-space vertices), the union box of every
-//              8 consecutive faces, the frame's reference depth and active pixel region.  Faces are Morton-ordered
-//              once at model creation, so consecutive faces are screen-space neighbours in any pose.
-//   sweep      block = 32 consecutive faces, 16 lanes per face walking the box row-major.  Per pixel two cached
-//              depth bounds lo <= hi: candidates <= lo go into ONE packed 64-bit integer per pixel
-//              (count << 50 | sum of -log2(1 - p) in 2^-24 fixed point; 32x32-pixel LDS window, one global atomic per
-//              touched pixel), candidates in (lo, hi] into the pixel's band list (<= 64 entries, staged per wave),
-//              candidates beyond hi are dropped unevaluated.  Integer adds commute: order-independent results.
-//   resolve    thread per pixel of the active region: with c = #{<= lo}, b = #band the K nearest are proved from
-//              counts (c <= K <= c + b) or the pixel is queued.
-//   band       half-wave per pixel: ranks the band entries, adds the K - c nearest, re-centres / narrows the bounds.
-//   select     wave per queued pixel: exact K nearest from scratch (union boxes -> face boxes -> evaluation ->
-//              candidates in LDS in face order -> K-th depth by linear-histogram refinement + exact ranks), new
-//              bounds sized to the current miss rate.  The cache is only ever a verified shortcut.
-//   bwd        face-parallel gather with the same box walk; the depth of the farthest included candidate is stored
-//              with the adjoint seed so that it applies exactly the forward's truncation.
-// ------------------------------------------------------------------------------------------------
-constexpr int kRectFaces = 8;             // faces per entry of the union-box index
-#ifndef SMALFIT_SWEEP_FACES
-#define SMALFIT_SWEEP_FACES 32
-#endif
-#ifndef SMALFIT_ACC_WIN
-#define SMALFIT_ACC_WIN 32
-#endif
-constexpr int kSweepFaces = SMALFIT_SWEEP_FACES;   // faces per sweep block
-constexpr int kAccWin = SMALFIT_ACC_WIN;  // LDS accumulator window edge (pixels); outside: global atomics
-constexpr int kCountShift = 50;
-constexpr float kLogFix = 16777216.0f;    // 2^24
-constexpr int kBandCap = 64;              // per-pixel list of candidates between the two cached depth bounds
-#ifndef SMALFIT_BAND_FILL
-#define SMALFIT_BAND_FILL 30
-#endif
-#ifndef SMALFIT_BAND_FILL_WIDE
-#define SMALFIT_BAND_FILL_WIDE 60
-#endif
-#ifndef SMALFIT_BAND_FILL_NARROW
-#define SMALFIT_BAND_FILL_NARROW 16
-#endif
-constexpr int kBandFill = SMALFIT_BAND_FILL;   // the select kernel sizes the band to hold at most this many entries ...
-constexpr int kBandFillWide = SMALFIT_BAND_FILL_WIDE, kBandFillNarrow = SMALFIT_BAND_FILL_NARROW;   // ... or these, by miss rate
-#ifndef SMALFIT_BAND_STAGE
-#define SMALFIT_BAND_STAGE 128
-#endif
-constexpr int kBandStage = SMALFIT_BAND_STAGE;   // band entries staged per wave in the sweep before a batched append
-#ifndef SMALFIT_BAND_HALF
-#define SMALFIT_BAND_HALF 8.0f
-#endif
-constexpr float kBandHalf = SMALFIT_BAND_HALF;   // initial half-width of the band, in mean depth gaps of the K nearest
-
-__device__ __forceinline__ unsigned orderable(float f) {
-  const unsigned u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float from_orderable(unsigned k) {
-  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
-}
-__device__ __forceinline__ float wave_prod(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v *= __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ bool box_contains(int2 b, int x, int y) {
-  return (b.x & 0xffff) <= x && x <= (b.x >> 16) && (b.y & 0xffff) <= y && y <= (b.y >> 16);
-}
-__device__ __forceinline__ unsigned long long pack_candidate(float d) {
-  // count in the top bits, -log2(1 - p) = -log2 sigmoid(d / sigma) in [0, 256) as 2^-24 fixed point.
-  // v_exp_f32 / v_log_f32 directly (1 ulp; the argument ranges need no denormal handling: 2^-|x| only matters while
-  // it is > 2^-24 next to 1).  One rounded term is off by <= 6e-8 relative in alpha, like a rounded multiplication.
-  const float x2 = d * (1.4426950408889634f / kSigma);
-  const float t = __builtin_amdgcn_exp2f(-fabsf(x2));
-  const float f = fminf(__builtin_amdgcn_logf(1.0f + t) - fminf(x2, 0.0f), 255.99998f);
-  return (1ull << kCountShift) | (unsigned long long)(unsigned)(f * kLogFix);
-}
-
-// p = sigmoid(-d / sigma) with the hardware exp2 / rcp (backward sweep)
-__device__ __forceinline__ float prob_fast(float d) {
-  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(d * (1.4426950408889634f / kSigma)));
-}
-
-// 5a: per-face validity, conservative pixel box, packed record; union box per 32 faces
-__global__ void __launch_bounds__(256)
-face_bbox_kernel(ModelDev m, int S, const float* __restrict__ proj, int2* __restrict__ fbox,
-                 float4* __restrict__ frec /*[M][F][3]*/, int4* __restrict__ brect /*[M][ceil(F/32)]*/,
-                 float* __restrict__ zc /*[M]*/, int* __restrict__ frect /*[M][4]: S - x0, x1 + 1, S - y0, y1 + 1 of the active region; 0 = empty*/,
-                 int* __restrict__ qcount /*[3]: select / band queue lengths, pixels resolve sent to select; reset here*/) {
-  const int f = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
-  if (blockIdx.x == 0 && n == 0 && threadIdx.x < 3) qcount[threadIdx.x] = 0;
-  const int Vp = m.Vp;
-  const float* px = proj + (size_t)n * 3 * Vp;
-  // reference depth of the frame (mean over 64 spread vertices).  The rasteriser orders candidates by pz - zc, which
-  // is the same order (the subtraction is exact for depths within a factor two) but keeps the cached per-pixel
-  // bounds valid when the whole animal moves along the view axis.
-  if (blockIdx.x == 0 && threadIdx.x < 64) {
-    const float zsum = wave_sum(px[2 * Vp + (int)(((long long)threadIdx.x * m.V) >> 6)]);
-    if (threadIdx.x == 0) zc[n] = zsum * (1.0f / 64.0f);
-  }
-  int2 box = make_int2(1, 1);     // c0=1 > c1=0 : empty
-  if (f < m.F) {
-    const int i0 = m.faces[f * 3], i1 = m.faces[f * 3 + 1], i2 = m.faces[f * 3 + 2];
-    const float ax = px[i0], ay = px[Vp + i0], az = px[2 * Vp + i0];
-    const float bx = px[i1], by = px[Vp + i1], bz = px[2 * Vp + i1];
-    const float cx = px[i2], cy = px[Vp + i2], cz = px[2 * Vp + i2];
-    FaceRec r;
-    const bool ok = make_face_rec(ax, ay, az, bx, by, bz, cx, cy, cz, r);
-    if (ok) {
-      const float xlo = fminf(ax, fminf(bx, cx)) - kBlurSqrt, xhi = fmaxf(ax, fmaxf(bx, cx)) + kBlurSqrt;
-      const float ylo = fminf(ay, fminf(by, cy)) - kBlurSqrt, yhi = fmaxf(ay, fmaxf(by, cy)) + kBlurSqrt;
-      // pixel centre x_p = 1 - (2c+1)/S  =>  c = ((1 - x_p) S - 1) / 2
-      const float fs = (float)S;
-      // (floor / ceil leave up to one pixel of slack either side: far more than the rounding of these bounds)
-      float c0 = floorf(((1.0f - xhi) * fs - 1.0f) * 0.5f);
-      float c1 = ceilf(((1.0f - xlo) * fs - 1.0f) * 0.5f);
-      float r0 = floorf(((1.0f - yhi) * fs - 1.0f) * 0.5f);
-      float r1 = ceilf(((1.0f - ylo) * fs - 1.0f) * 0.5f);
-      c0 = fminf(fmaxf(c0, 0.f), fs - 1.f); c1 = fminf(fmaxf(c1, -1.f), fs - 1.f);
-      r0 = fminf(fmaxf(r0, 0.f), fs - 1.f); r1 = fminf(fmaxf(r1, -1.f), fs - 1.f);
-      const bool finite = (xlo == xlo) && (xhi == xhi) && (ylo == ylo) && (yhi == yhi);
-      const bool onscreen = finite && (xhi >= -1.0f) && (xlo <= 1.0f) && (yhi >= -1.0f) && (ylo <= 1.0f) &&
-                            (c1 >= c0) && (r1 >= r0);
-      if (onscreen) box = make_int2((int)c0 | ((int)c1 << 16), (int)r0 | ((int)r1 << 16));
-    }
-    fbox[(size_t)n * m.F + f] = box;
-    float4* o = frec + ((size_t)n * m.F + f) * 3;
-    o[0] = make_float4(__int_as_float(box.x), __int_as_float(box.y), ax, ay);
-    o[1] = make_float4(az, bx, by, bz);
-    o[2] = make_float4(cx, cy, cz, 0.f);
-  }
-  // union box of each group of kRectFaces consecutive faces (sub-wave shuffle reduction)
-  const bool live = (box.x & 0xffff) <= (box.x >> 16);
-  int x0 = live ? (box.x & 0xffff) : 0x7fff, x1 = live ? (box.x >> 16) : -1;
-  int y0 = live ? (box.y & 0xffff) : 0x7fff, y1 = live ? (box.y >> 16) : -1;
-#pragma unroll
-  for (int o = kRectFaces / 2; o > 0; o >>= 1) {
-    x0 = min(x0, __shfl_xor(x0, o, kRectFaces)); x1 = max(x1, __shfl_xor(x1, o, kRectFaces));
-    y0 = min(y0, __shfl_xor(y0, o, kRectFaces)); y1 = max(y1, __shfl_xor(y1, o, kRectFaces));
-  }
-  if ((threadIdx.x & (kRectFaces - 1)) == 0 && f < m.F)
-    brect[(size_t)n * ((m.F + kRectFaces - 1) / kRectFaces) + f / kRectFaces] = make_int4(x0, x1, y0, y1);
-  // the frame's active region: pixel box of ALL projected vertices, blur-expanded -- a superset of every face box, so
-  // pixels outside it have no candidate at all.  Block 0 of the frame scans the vertices (no atomics).
-  if (blockIdx.x == 0) {
-    __shared__ float rr[4][4];
-    float xlo = 3.0e38f, xhi = -3.0e38f, ylo = 3.0e38f, yhi = -3.0e38f;
-    for (int v = threadIdx.x; v < m.V; v += 256) {
-      const float x = px[v], y = px[Vp + v];
-      xlo = fminf(xlo, x); xhi = fmaxf(xhi, x); ylo = fminf(ylo, y); yhi = fmaxf(yhi, y);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      xlo = fminf(xlo, __shfl_xor(xlo, o, 64)); xhi = fmaxf(xhi, __shfl_xor(xhi, o, 64));
-      ylo = fminf(ylo, __shfl_xor(ylo, o, 64)); yhi = fmaxf(yhi, __shfl_xor(yhi, o, 64));
-    }
-    if ((threadIdx.x & 63) == 0) { float* q = rr[threadIdx.x >> 6]; q[0] = xlo; q[1] = xhi; q[2] = ylo; q[3] = yhi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int w = 1; w < 4; ++w) { xlo = fminf(xlo, rr[w][0]); xhi = fmaxf(xhi, rr[w][1]); ylo = fminf(ylo, rr[w][2]); yhi = fmaxf(yhi, rr[w][3]); }
-      xlo -= kBlurSqrt; xhi += kBlurSqrt; ylo -= kBlurSqrt; yhi += kBlurSqrt;
-      const float fs = (float)S;
-      const float c0 = fmaxf(floorf(((1.0f - xhi) * fs - 1.0f) * 0.5f), 0.f), c1 = fminf(ceilf(((1.0f - xlo) * fs - 1.0f) * 0.5f), fs - 1.f);
-      const float r0 = fmaxf(floorf(((1.0f - yhi) * fs - 1.0f) * 0.5f), 0.f), r1 = fminf(ceilf(((1.0f - ylo) * fs - 1.0f) * 0.5f), fs - 1.f);
-      int4 o = make_int4(0, 0, 0, 0);              // (S - c0, c1 + 1, S - r0, r1 + 1); zeros = empty
-      if (c0 <= c1 && r0 <= r1) o = make_int4(S - (int)c0, (int)c1 + 1, S - (int)r0, (int)r1 + 1);
-      *reinterpret_cast<int4*>(frect + n * 4) = o;
-    }
-  }
-}
-
-__device__ __forceinline__ bool load_face_rec(const float4* __restrict__ fr, FaceRec& r, int2& box) {
-  const float4 a = fr[0], b = fr[1], c = fr[2];
-  box = make_int2(__float_as_int(a.x), __float_as_int(a.y));
-  return make_face_rec(a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, r);
-}
-
-// 5b: sweep.  Each pixel carries two cached depth bounds lo <= hi from the last exact selection (zband; +inf
-// while the pixel never had more than K candidates).  Candidates not farther than lo are accumulated into ONE packed
-// integer (count << 50 | log sum); candidates in (lo, hi] are appended to the pixel's short band list; farther ones
-// are dropped.  raster_resolve_kernel proves from the counts that the K nearest are {<= lo} + the nearest few of the
-// band, or sends the pixel to the exact selection.
-__global__ void __launch_bounds__(256)
-raster_sweep_kernel(int F, int S, const float4* __restrict__ frec, const float* __restrict__ zc, const float2* __restrict__ zband,
-                    unsigned long long* __restrict__ gacc /*[M][S*S]*/, unsigned* __restrict__ bcnt /*[M][S*S]*/,
-                    float2* __restrict__ blist /*[M][S*S][kBandCap]*/) {
-  __shared__ __attribute__((aligned(16))) FaceRec recs[kSweepFaces];
-  __shared__ int2 boxes[kSweepFaces];
-  __shared__ unsigned long long acc[kAccWin * kAccWin];   // near candidates: count << 50 | log sum
-  __shared__ int rect[4];
-  // band entries are staged per wave and appended to the per-pixel lists in batches: the append needs the value
-  // returned by a global atomic, and one such round trip per patch would stall the inner loop
-  __shared__ float2 st_e[4][kBandStage];
-  __shared__ int st_p[4][kBandStage];
-  __shared__ int st_n[4];
-  const int n = blockIdx.y, t = threadIdx.x;
-  const int f0 = blockIdx.x * kSweepFaces;
-  if (t < 4) { rect[t] = (t & 1) ? -1 : 0x7fff; st_n[t] = 0; }   // x0, x1, y0, y1
-  for (int i = t; i < kAccWin * kAccWin; i += 256) acc[i] = 0ull;
-  __syncthreads();
-  if (t < kSweepFaces) {
-    int2 box = make_int2(1, 1);
-    if (f0 + t < F) {
-      FaceRec r;
-      load_face_rec(frec + ((size_t)n * F + f0 + t) * 3, r, box);
-      recs[t] = r;
-    }
-    boxes[t] = box;
-    if ((box.x & 0xffff) <= (box.x >> 16)) {
-      atomicMin(&rect[0], box.x & 0xffff); atomicMax(&rect[1], box.x >> 16);
-      atomicMin(&rect[2], box.y & 0xffff); atomicMax(&rect[3], box.y >> 16);
-    }
-  }
-  __syncthreads();
-  if (rect[1] < rect[0]) return;                        // no face of this block is on screen
-  const int wx0 = rect[0], wy0 = rect[2];
-  const size_t fbase = (size_t)n * S * S;
-  unsigned long long* ga = gacc + fbase;
-  const float2* zbp = zband + fbase;
-  const int sub = t & 15, grp = t >> 4;
-  const float inv_s = 1.0f / (float)S;
-  const int wv = t >> 6, lane = t & 63;
-  const float zcn = zc[n];
-  auto flush_band = [&]() {                              // called with the wave converged
-    const int cnt = min(__builtin_amdgcn_readfirstlane(st_n[wv]), kBandStage);
-    for (int i = lane; i < cnt; i += 64) {
-      const size_t pi = fbase + (size_t)st_p[wv][i];
-      const unsigned slot = atomicAdd(&bcnt[pi], 1u);
-      if (slot < (unsigned)kBandCap) blist[pi * kBandCap + slot] = st_e[wv][i];
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) st_n[wv] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  };
-  for (int step = 0; step < kSweepFaces / 16; ++step) {
-    if (__builtin_amdgcn_readfirstlane(st_n[wv]) >= kBandStage / 2) flush_band();
-    const int k = step * 16 + grp;
-    const int2 box = boxes[k];
-    const int c0 = box.x & 0xffff, c1 = box.x >> 16, r0 = box.y & 0xffff, r1 = box.y >> 16;
-    if (c0 > c1) continue;
-    const FaceRec rk = recs[k];                      // in registers: the LDS atomics below would force a reload per pixel
-    // the box's pixels in row-major order, 16 at a time (no lane idles except in the last round)
-    // (row, col) advance by 16 pixels per round: 16 = srow * bw + scol, one conditional wrap
-    const int bw = c1 - c0 + 1, npx = bw * (r1 - r0 + 1);
-    const int srow = 16 / bw, scol = 16 - srow * bw;
-    int ry = sub / bw, cx = sub - ry * bw;
-    for (int q = sub; q < npx; q += 16) {
-      {
-        const int row = r0 + ry, col = c0 + cx;
-        cx += scol; ry += srow;
-        if (cx >= bw) { cx -= bw; ++ry; }
-        const float2 zb = zbp[row * S + col];
-        const float ppx = pix_to_ndc(col, inv_s), ppy = pix_to_ndc(row, inv_s);
-        const float rz = face_pixel_depth(rk, ppx, ppy) - zcn;   // depth relative to the frame reference
-        if (!(rz <= zb.y)) continue;                   // beyond the pixel's far bound: dropped whatever its distance
-        PixEval e;
-        if (!face_pixel_eval(rk, ppx, ppy, e)) continue;
-        if (rz <= zb.x) {
-          const int lxw = col - wx0, lyw = row - wy0;
-          if (lxw < kAccWin && lyw < kAccWin) atomicAdd(&acc[lyw * kAccWin + lxw], pack_candidate(e.d));
-          else atomicAdd(&ga[row * S + col], pack_candidate(e.d));
-        } else {
-          const int sl = atomicAdd(&st_n[wv], 1);
-          if (sl < kBandStage) {
-            st_p[wv][sl] = row * S + col;
-            st_e[wv][sl] = make_float2(rz, e.d);
-          } else {                                       // staging buffer full: append directly
-            const size_t pi = fbase + (size_t)(row * S + col);
-            const unsigned slot = atomicAdd(&bcnt[pi], 1u);
-            if (slot < (unsigned)kBandCap) blist[pi * kBandCap + slot] = make_float2(rz, e.d);
-          }
-        }
-      }
-    }
-  }
-  flush_band();
-  __syncthreads();
-  const int ww = min(kAccWin, rect[1] - wx0 + 1), wh = min(kAccWin, rect[3] - wy0 + 1);
-  for (int i = t; i < wh * kAccWin; i += 256) {
-    const int lyw = i / kAccWin, lxw = i % kAccWin;
-    if (lxw >= ww) continue;
-    const unsigned long long v = acc[lyw * kAccWin + lxw];
-    if (v) atomicAdd(&ga[(wy0 + lyw) * S + wx0 + lxw], v);
-  }
-}
-
-// The queues of the band / select kernels are filled in a non-deterministic order, so which block sums which pixel
-// varies from run to run: their loss partials are kept as 2^-40 fixed-point integers (integer adds commute), which
-// makes the reported loss bit-reproducible like everything else.
-constexpr float kLossFix = 1099511627776.0f;    // 2^40: a weighted per-pixel loss of 1 over 8M pixels still fits int64
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const int lo = __shfl_xor((int)(v & 0xffffffffll), o, 64), hi = __shfl_xor((int)(v >> 32), o, 64);
-    v += ((long long)hi << 32) | (unsigned int)lo;
-  }
-  return v;
-}
-
-// 5c: resolve.  With c = #candidates <= lo and b = #band entries of a pixel, the K nearest are known exactly when
-// (no bounds yet: c <= K)  or  (c <= K <= c + b: {<= lo} plus the K - c nearest band entries)  or  (hi = +inf and
-// c + b < K: everything).  Otherwise -- more than K below lo, a band overflow, an unknown number beyond hi, or a
-// depth tie at the cut -- raster_select_kernel redoes the pixel from scratch and refreshes its bounds.
-// raster_resolve_kernel is thread-per-pixel: it finishes the pixels that need no sorting and appends the others to
-// the band queue or the select queue (one global atomic per block and queue).
-__global__ void __launch_bounds__(256)
-raster_resolve_kernel(int S, int M, int window, float w_sil, unsigned long long* __restrict__ gacc,
-                      unsigned* __restrict__ bcnt, const int* __restrict__ frect, const float2* __restrict__ zband,
-                      const float* __restrict__ tsil, float* __restrict__ sil_out,
-                      float2* __restrict__ gz, float* __restrict__ blk_loss, int* __restrict__ qcount /*[0] select, [1] band*/,
-                      int* __restrict__ queue, int* __restrict__ bqueue, int* __restrict__ stats /*developer counters or null*/) {
-  __shared__ int qn[2], qbase[2];
-  __shared__ float red[16];
-  constexpr int K = kFacesPerPixel;
-  constexpr unsigned long long kSumMask = (1ull << kCountShift) - 1ull;
-  const float kInf = __int_as_float(0x7f800000);
-  const int n = blockIdx.y;
-  const int TX = (S + 15) / 16;
-  const int tx = blockIdx.x % TX, ty = blockIdx.x / TX;
-  const int t = threadIdx.x;
-  const int col = tx * 16 + (t & 15), row = ty * 16 + (t >> 4);
-  const bool inimg = (col < S) && (row < S);
-  const size_t pi = ((size_t)n * S + row) * S + col;
-  if (t < 2) qn[t] = 0;
-  __syncthreads();
-  int action = 0, slot = 0;                        // 0: finished from the sum alone, 1: select queue, 2: band queue
-  float l = 0.f;
-  // tiles outside the frame's active region hold no candidate: silhouette 0, nothing else to read or write
-  const int4 fr = *reinterpret_cast<const int4*>(frect + n * 4);
-  const bool active = fr.y > 0 && tx * 16 <= fr.y - 1 && tx * 16 + 15 >= S - fr.x && ty * 16 <= fr.w - 1 && ty * 16 + 15 >= S - fr.z;
-  if (inimg && !active) {
-    if (sil_out) sil_out[pi] = 0.f;
-    if (tsil) l = fabsf(tsil[pi]);
-  }
-  if (inimg && active) {
-    const unsigned long long vb = gacc[pi];
-    const int c = (int)(vb >> kCountShift);
-    const int b = (int)bcnt[pi];
-    const float2 zb = zband[pi];
-    const int need = K - c;
-    float zthr = kInf;
-    if (!(zb.x < kInf)) action = (c <= K) ? 0 : 1;
-    else if (need < 0 || b > kBandCap) action = 1;
-    else if (need == 0) zthr = zb.x;                              // exactly K at or below lo
-    else if (need > b) action = (zb.y < kInf) ? 1 : (b == 0 ? 0 : 2);   // hi = +inf: fewer than K candidates in all
-    else action = 2;
-    if (stats && zb.x < kInf) {
-      atomicAdd(&stats[1], 1);
-      if (action != 1) { atomicAdd(&stats[2], 1); atomicAdd(&stats[3], b); }
-      else atomicAdd(&stats[need < 0 ? 4 : (b > kBandCap ? 5 : 6)], 1);
-    }
-    if (action == 0) {
-      const float alpha = (c > 0) ? (float)exp2(-(double)(vb & kSumMask) * (1.0 / (double)kLogFix)) : 1.0f;
-      const float sil = 1.0f - alpha;
-      if (sil_out) sil_out[pi] = sil;
-      float gx = 0.f;
-      if (tsil) {
-        const float diff = sil - tsil[pi];
-        l = fabsf(diff);
-        const float sgn = (diff > 0.f) ? 1.0f : ((diff < 0.f) ? -1.0f : 0.0f);
-        gx = -(w_sil / ((float)frame_window_size(n, M, window) * (float)S * (float)S)) * sgn * alpha * (1.0f / kSigma);
-      }
-      gz[pi] = make_float2(gx, zthr);
-    } else {
-      slot = atomicAdd(&qn[action - 1], 1);
-    }
-    // the accumulators are left zero for the next sweep by whoever reads them last (band pixels: raster_band_kernel)
-    if (action != 2) {
-      if (vb) gacc[pi] = 0ull;
-      if (b) bcnt[pi] = 0u;
-    }
-  }
-  __syncthreads();
-  if (t < 2) qbase[t] = qn[t] > 0 ? atomicAdd(&qcount[t], qn[t]) : 0;
-  if (t == 2 && qn[0] > 0) atomicAdd(&qcount[2], qn[0]);   // [2] stays fixed while the band kernel appends its failures to [0]
-  __syncthreads();
-  if (action == 1) queue[qbase[0] + slot] = (int)pi;
-  else if (action == 2) bqueue[qbase[1] + slot] = (int)pi;
-  if (blk_loss) {
-    l = block_sum(l, red);
-    if (t == 0) blk_loss[(size_t)n * gridDim.x + blockIdx.x] = l;
-  }
-}
-
-// 5c': band.  Persistent grid, one half-wave per queued pixel, two band entries per lane (coalesced 256-byte reads):
-// rank by counting against an LDS broadcast of the depths, include the K - c nearest, check for a tie at the cut,
-// then re-centre (and, when the pose moves little, narrow) the pixel's bounds.
-constexpr int kBandBlocks = 1024;
-__global__ void __launch_bounds__(256)
-raster_band_kernel(int S, int M, int window, float w_sil, unsigned long long* __restrict__ gacc,
-                   unsigned* __restrict__ bcnt, const float2* __restrict__ blist,
-                   const float* __restrict__ tsil, float* __restrict__ sil_out, float2* __restrict__ gz,
-                   float2* __restrict__ zband, int* __restrict__ qcount, int* __restrict__ queue,
-                   const int* __restrict__ bqueue, long long* __restrict__ bloss /*[gridDim.x]: weighted |sil - target| per block in 2^-40 fixed point, or null*/) {
-  static_assert(kBandCap == 64, "two band entries per lane of a half-wave");
-  __shared__ __attribute__((aligned(16))) float zs[8][64];
-  __shared__ float red[16];
-  constexpr int K = kFacesPerPixel;
-  constexpr unsigned long long kSumMask = (1ull << kCountShift) - 1ull;
-  const float kInf = __int_as_float(0x7f800000);
-  const int t = threadIdx.x, hw = t >> 5, hl = t & 31;
-  const int nb = qcount[1];
-  const int npix = S * S;
-  long long lacc = 0;
-  // band population this evaluation's miss rate calls for (same rule as the selection kernel; qcount[2] does not
-  // change while this kernel runs, so the decision is the same in every run)
-  const float miss = (float)qcount[2] / (float)max(qcount[2] + nb, 1);
-  const int fill_target = (miss > 0.12f) ? kBandFillWide : ((miss > 0.02f) ? kBandFill : kBandFillNarrow);
-  // Software pipeline over this half-wave's pixels: the operands of pixel j + 1 (five loads that depend on its queue
-  // entry) are in flight while pixel j is ranked; the queue entry itself is fetched two pixels ahead.
-  const int jstep = gridDim.x * 8;
-  const int j0 = blockIdx.x * 8 + hw;
-  struct Operands { int gp; unsigned long long vb; int b; float ts; float2 zb, v, u; };
-  auto fetch = [&](int gp) {
-    Operands o;
-    o.gp = gp;
-    const size_t pi = (size_t)gp;
-    o.vb = gacc[pi];
-    o.b = (int)bcnt[pi];
-    o.ts = tsil ? tsil[pi] : 0.f;
-    o.zb = zband[pi];
-    o.v = blist[pi * kBandCap + hl];                      // list slots are read whether or not they are occupied
-    o.u = blist[pi * kBandCap + 32 + hl];
-    return o;
-  };
-  Operands nxt = fetch((j0 < nb) ? bqueue[j0] : 0);
-  int gp_after = (j0 + jstep < nb) ? bqueue[j0 + jstep] : 0;
-  for (int j = j0; j < nb; j += jstep) {
-    const Operands cur = nxt;
-    if (j + jstep < nb) nxt = fetch(gp_after);
-    if (j + 2 * jstep < nb) gp_after = bqueue[j + 2 * jstep];
-    const int gp = cur.gp;
-    const size_t pi = (size_t)gp;
-    // a lane holds entries hl and hl + 32 -- the second half only exists for wide bands (large parameter steps)
-    const unsigned long long vb = cur.vb;
-    const int b = cur.b;
-    const float ts = cur.ts;
-    const float2 zb_old = cur.zb;
-    float2 v = cur.v, u = cur.u;
-    if (hl >= b) v = make_float2(kInf, 0.f);
-    if (hl + 32 >= b) u = make_float2(kInf, 0.f);
-    const bool wide = b > 32;                              // uniform over the half-wave
-    const int need = min(K - (int)(vb >> kCountShift), b);
-    if (hl == 0) { gacc[pi] = 0ull; bcnt[pi] = 0u; }        // zero for the next sweep
-    zs[hw][hl] = v.x;
-    zs[hw][32 + hl] = u.x;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    int rank = 0, rank_u = 0;
-#pragma unroll
-    for (int k4 = 0; k4 < 8; ++k4) {
-      const float4 q = *reinterpret_cast<const float4*>(&zs[hw][k4 * 4]);
-      rank += (q.x < v.x) + (q.y < v.x) + (q.z < v.x) + (q.w < v.x);
-    }
-    if (wide) {
-#pragma unroll
-      for (int k4 = 0; k4 < 8; ++k4) {
-        const float4 q = *reinterpret_cast<const float4*>(&zs[hw][k4 * 4]);
-        const float4 p = *reinterpret_cast<const float4*>(&zs[hw][32 + k4 * 4]);
-        rank += (p.x < v.x) + (p.y < v.x) + (p.z < v.x) + (p.w < v.x);
-        rank_u += (q.x < u.x) + (q.y < u.x) + (q.z < u.x) + (q.w < u.x) + (p.x < u.x) + (p.y < u.x) + (p.z < u.x) + (p.w < u.x);
-      }
-    }
-    const bool in = (hl < b) && (rank < need), in_u = (hl + 32 < b) && (rank_u < need);
-    unsigned long long pv = in ? (pack_candidate(v.y) & kSumMask) : 0ull;
-    if (in_u) pv += pack_candidate(u.y) & kSumMask;
-    int s_lo = (int)(pv & 0x1ffffffull), s_hi = (int)(pv >> 25);
-    float zin = fmaxf(in ? v.x : -kInf, in_u ? u.x : -kInf);
-    float zout = fminf((hl < b && !in) ? v.x : kInf, (hl + 32 < b && !in_u) ? u.x : kInf);
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
-      s_lo += __shfl_xor(s_lo, o, 32); s_hi += __shfl_xor(s_hi, o, 32);
-      zin = fmaxf(zin, __shfl_xor(zin, o, 32)); zout = fminf(zout, __shfl_xor(zout, o, 32));
-    }
-    // ranks ignore ties: with a tie at the cut the number of entries <= zin is not `need`; let the selection decide
-    const unsigned long long bal = __ballot((hl < b) && (v.x <= zin));
-    const unsigned long long bal_u = __ballot((hl + 32 < b) && (u.x <= zin));
-    const int taken = __popc((unsigned)(bal >> (32 * (hw & 1)))) + __popc((unsigned)(bal_u >> (32 * (hw & 1))));
-    if (hl == 0) {
-      if (taken == need && zin < zout) {
-        const unsigned long long sum = (vb & kSumMask) + ((unsigned long long)s_hi << 25) + (unsigned long long)s_lo;
-        const float alpha = (float)exp2(-(double)sum * (1.0 / (double)kLogFix));
-        const float sil = 1.0f - alpha;
-        if (sil_out) sil_out[pi] = sil;
-        float gx = 0.f;
-        if (tsil) {
-          const int n = gp / npix;
-          const float wn = w_sil / ((float)frame_window_size(n, M, window) * (float)S * (float)S);
-          const float diff = sil - ts;
-          lacc += (long long)(fabsf(diff) * wn * kLossFix);
-          const float sgn = (diff > 0.f) ? 1.0f : ((diff < 0.f) ? -1.0f : 0.0f);
-          gx = -wn * sgn * alpha * (1.0f / kSigma);
-        }
-        gz[pi] = make_float2(gx, zin);
-        // re-centre the pixel's bounds on the depth of its K-th nearest as just determined (zin), keeping the
-        // half-width (or narrowing it when it holds more candidates than the current pose motion calls for): the band
-        // follows the surface from iteration to iteration.  Bounds are hints -- any value is valid.
-        if (zb_old.y < kInf) {
-          float half = 0.5f * (zb_old.y - zb_old.x);
-          if (4 * b > 5 * fill_target) half *= (float)fill_target / (float)b;   // wider than the pose motion needs now
-          zband[pi] = make_float2(zin - half, zin + half);
-        }
-      } else {
-        queue[atomicAdd(&qcount[0], 1)] = gp;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (bloss) {
-    __shared__ long long lred[4];
-    const long long ws = wave_sum_i64(lacc);
-    if ((t & 63) == 0) lred[t >> 6] = ws;
-    __syncthreads();
-    if (t == 0) bloss[blockIdx.x] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
-  }
-}
-
-// 5d: select.  Persistent grid; one wave per queued pixel: it walks the union boxes (8 faces each)
-// containing the pixel, evaluates those faces (lane per face, record loads software-prefetched), compacts
-// the candidates into LDS in face order, finds the K-th smallest depth exactly (histogram over a linear quantisation
-// of the depth range, narrowed to <= 64 entries, then exact ranks) and multiplies the K nearest (1 - p) in a fixed order.
-#ifndef SMALFIT_CAND_CAP
-#define SMALFIT_CAND_CAP 1024
-#endif
-#ifndef SMALFIT_COVER_CAP
-#define SMALFIT_COVER_CAP 2048
-#endif
-constexpr int kCandCap = SMALFIT_CAND_CAP;   // candidates per pixel kept in LDS; beyond: multi-pass re-evaluation
-constexpr int kHitCap = 2 * SMALFIT_CAND_CAP < 1024 ? 2 * SMALFIT_CAND_CAP : 1024;   // union boxes containing a pixel kept in LDS (aliases the candidate buffer)
-constexpr int kCoverCap = SMALFIT_COVER_CAP;   // faces whose box covers the pixel, kept in LDS (u16 ids)
-
-constexpr int kSelWaves = 2;              // waves per select block: 13 KB of LDS per wave -> 6 blocks (12 waves) per CU
-
-__global__ void __launch_bounds__(64 * kSelWaves)
-raster_select_kernel(int F, int S, int M, int window, float w_sil, const float4* __restrict__ frec, const float* __restrict__ zc,
-                     const int4* __restrict__ brect, const int2* __restrict__ fbox, const int* __restrict__ qcount,
-                     const int* __restrict__ queue, const float* __restrict__ tsil,
-                     float* __restrict__ sil_out, float2* __restrict__ gz, float2* __restrict__ zband,
-                     long long* __restrict__ qloss /*[gridDim.x]: weighted |sil - target| per block in 2^-40 fixed point, or null*/, int dbg) {
-  __shared__ unsigned hist[kSelWaves][256];
-  __shared__ float2 cand[kSelWaves][kCandCap];
-  __shared__ unsigned short fids[kSelWaves][kCoverCap];
-  // the union-box hit list is consumed (stage A) before the first candidate is written (stage B): share storage
-  int (*hits)[2 * kCandCap] = reinterpret_cast<int (*)[2 * kCandCap]>(&cand[0][0]);
-  static_assert(kHitCap <= 2 * kCandCap, "hit list must fit in the candidate buffer");
-  __shared__ long long wloss[kSelWaves];
-  long long lacc = 0;
-  constexpr int K = kFacesPerPixel;
-  constexpr int RC = kCandCap / 64;
-  constexpr int RPI = 64 / kRectFaces;      // union boxes handled per wave iteration
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int nq = *qcount;
-  // how many candidates the new bands may hold: wide bands survive large parameter steps (stage 1) but cost list
-  // appends and band sorting in every later evaluation, narrow ones are cheap while the pose barely moves.  The share
-  // of bounded pixels that needed this kernel in the current evaluation decides.
-  const int nbandq = qcount[1];
-  const float miss = (float)nq / (float)max(nq + nbandq, 1);
-  const int band_fill = (miss > 0.12f) ? kBandFillWide : ((miss > 0.02f) ? kBandFill : kBandFillNarrow);
-  const int nrect = (F + kRectFaces - 1) / kRectFaces;
-  const float inv_s = 1.0f / (float)S;
-  const int npix = S * S;
-  // XCD-affine split of the queue: workgroups are dealt to the 8 XCDs round-robin, and the queue is roughly
-  // frame-ordered (resolve blocks of a frame append together), so XCD x takes the x-th eighth of it and its L2 only
-  // has to hold the face records of ~M/8 frames instead of all of them.
-  const int xcd = blockIdx.x & 7, nbx = (gridDim.x + 7 - xcd) >> 3;       // blocks on this XCD (grid >= 8)
-  const int q_lo = (int)(((long long)nq * xcd) >> 3), q_hi = (int)(((long long)nq * (xcd + 1)) >> 3);
-  for (int qi = q_lo + (blockIdx.x >> 3) * kSelWaves + w; qi < q_hi; qi += nbx * kSelWaves) {
-    const int gp = queue[qi];
-    const int n = gp / npix, pix = gp % npix;
-    const int pcol = pix % S, prow = pix / S;
-    const float ppx = pix_to_ndc(pcol, inv_s), ppy = pix_to_ndc(prow, inv_s);
-    const float zcn = zc[n];
-    const int4* br = brect + (size_t)n * nrect;
-    const float4* fr = frec + (size_t)n * F * 3;
-    // union boxes containing the pixel (ascending); 8 independent loads in flight per round
-    int nh = 0;
-    for (int r0 = 0; r0 < nrect; r0 += 512) {
-      int4 b[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int ri = r0 + u * 64 + lane;
-        b[u] = (ri < nrect) ? br[ri] : make_int4(1, 0, 1, 0);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const bool hit = b[u].x <= pcol && pcol <= b[u].y && b[u].z <= prow && prow <= b[u].w;
-        const unsigned long long bal = __ballot(hit);
-        if (hit) { const int pos = nh + __popcll(bal & ((1ull << lane) - 1ull)); if (pos < kHitCap) hits[w][pos] = r0 + u * 64 + lane; }
-        nh += __popcll(bal);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (dbg & 1) continue;
-    // faces whose pixel box covers the pixel (ascending ids): 8-byte box test only, nothing evaluated yet
-    const int2* fb = fbox + (size_t)n * F;
-    int ncov = 0;
-    if (nh <= kHitCap) {
-      for (int j = 0; j < nh; j += 8 * RPI) {
-        int ff[8];
-        int2 bx[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int hj = j + u * RPI + lane / kRectFaces;
-          ff[u] = -1;
-          bx[u] = make_int2(1, 1);
-          if (hj < nh) {
-            const int f = hits[w][hj] * kRectFaces + (lane & (kRectFaces - 1));
-            if (f < F) { ff[u] = f; bx[u] = fb[f]; }
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const bool cov = ff[u] >= 0 && box_contains(bx[u], pcol, prow);
-          const unsigned long long bal = __ballot(cov);
-          if (cov) { const int pos = ncov + __popcll(bal & ((1ull << lane) - 1ull)); if (pos < kCoverCap) fids[w][pos] = (unsigned short)ff[u]; }
-          ncov += __popcll(bal);
-        }
-      }
-    }
-    if (dbg & 2) continue;
-    const bool compact = (nh <= kHitCap) && (ncov <= kCoverCap) && (F <= 65536);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // visit every candidate of the pixel in face order: fn(valid, pz, d, face) is called wave-wide
-    auto scan_candidates = [&](auto&& fn) {
-      if (compact) {
-        // records of two rounds (128 faces) in flight
-        float4 pa[2], pb[2], pc[2];
-        bool plive[2];
-        auto prefetch = [&](int j, int slot) {
-          plive[slot] = (j + lane) < ncov;
-          if (plive[slot]) {
-            const int ff = fids[w][j + lane];
-            pa[slot] = fr[(size_t)ff * 3]; pb[slot] = fr[(size_t)ff * 3 + 1]; pc[slot] = fr[(size_t)ff * 3 + 2];
-          }
-        };
-        auto consume = [&](int j, int slot) {
-          const float4 a = pa[slot], b = pb[slot], c = pc[slot];
-          const bool live = plive[slot];
-          const int cur_ff = live ? (int)fids[w][j + lane] : 0;
-          if (j + 128 < ncov) prefetch(j + 128, slot);
-          bool ok = false;
-          PixEval e; e.pz = 0.f; e.d = 0.f;
-          if (live) {
-            FaceRec r;
-            make_face_rec(a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, r);
-            ok = face_pixel_eval(r, ppx, ppy, e);
-          }
-          fn(ok, e.pz - zcn, e.d, cur_ff);
-        };
-        prefetch(0, 0);
-        if (64 < ncov) prefetch(64, 1);
-        for (int j = 0; j < ncov; j += 128) {
-          consume(j, 0);
-          if (j + 64 < ncov) consume(j + 64, 1);
-        }
-      } else {                      // pathological: walk every face
-        for (int f0 = 0; f0 < F; f0 += 64) {
-          const int ff = f0 + lane;
-          bool ok = false;
-          PixEval e; e.pz = 0.f; e.d = 0.f;
-          if (ff < F) {
-            FaceRec r; int2 box;
-            load_face_rec(fr + (size_t)ff * 3, r, box);
-            if (box_contains(box, pcol, prow)) ok = face_pixel_eval(r, ppx, ppy, e);
-          }
-          fn(ok, e.pz - zcn, e.d, ff);
-        }
-      }
-    };
-    int nc = 0;
-    const float kInf = __int_as_float(0x7f800000);
-    float zmn = kInf, zmx = -kInf;                      // depth range of the candidates
-    scan_candidates([&](bool ok, float pz, float d, int ff) {
-      (void)ff;
-      const unsigned long long bal = __ballot(ok);
-      if (ok) {
-        const int pos = nc + __popcll(bal & ((1ull << lane) - 1ull));
-        if (pos < kCandCap) cand[w][pos] = make_float2(pz, one_minus_prob(d));
-        zmn = fminf(zmn, pz); zmx = fmaxf(zmx, pz);
-      }
-      nc += __popcll(bal);
-    });
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { zmn = fminf(zmn, __shfl_xor(zmn, o, 64)); zmx = fmaxf(zmx, __shfl_xor(zmx, o, 64)); }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (dbg & 4) continue;
-    const bool cached = nc <= kCandCap;
-    // visit every candidate wave-wide: fn(valid, depth, 1 - p); from LDS, or by re-evaluation when they did not fit
-    auto visit = [&](auto&& fn) {
-      if (cached) {
-#pragma unroll 4
-        for (int i = 0; i < RC; ++i) {
-          const int j = lane + 64 * i;
-          if (64 * i >= nc) break;
-          const float2 ev = (j < nc) ? cand[w][j] : make_float2(0.f, 1.f);
-          fn(j < nc, ev.x, ev.y);
-        }
-      } else {
-        scan_candidates([&](bool ok, float pz, float d, int ff) { (void)ff; fn(ok, pz, ok ? one_minus_prob(d) : 1.0f); });
-      }
-    };
-    // ---- depth of the K-th nearest: histogram over a linear quantisation of the current depth range (monotone, so the
-    // K-th lies in the bin where the running count crosses K), narrowed until that bin holds at most 64 candidates,
-    // which are then ranked exactly.  Usually one histogram pass.
-    float zk = kInf;
-    if (nc > K) {
-      float rlo = zmn, rhi = zmx;
-      int need = K;
-      float* sel = reinterpret_cast<float*>(&hist[w][0]);
-      for (int round = 0; round < 64; ++round) {
-        if (!(rhi > rlo)) { zk = rlo; break; }            // everything left has the same depth
-        const float scale = 256.0f / (rhi - rlo);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) hist[w][lane * 4 + i] = 0u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        visit([&](bool ok, float z, float omp) {
-          (void)omp;
-          if (ok && z >= rlo && z <= rhi) atomicAdd(&hist[w][min(255, (int)((z - rlo) * scale))], 1u);
-        });
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const unsigned h0 = hist[w][lane * 4], h1 = hist[w][lane * 4 + 1], h2 = hist[w][lane * 4 + 2], h3 = hist[w][lane * 4 + 3];
-        const int s4 = (int)(h0 + h1 + h2 + h3);
-        int incl = s4;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const int v = __shfl_up(incl, d, 64);
-          if (lane >= d) incl += v;
-        }
-        const int excl = incl - s4;
-        const bool mine = (excl < need) && (need <= incl);
-        int digit = 0, below = 0, cnt = 0;
-        if (mine) {
-          int cm = excl;
-          if (cm + (int)h0 >= need) { digit = lane * 4; below = cm; cnt = (int)h0; }
-          else { cm += (int)h0;
-            if (cm + (int)h1 >= need) { digit = lane * 4 + 1; below = cm; cnt = (int)h1; }
-            else { cm += (int)h1;
-              if (cm + (int)h2 >= need) { digit = lane * 4 + 2; below = cm; cnt = (int)h2; }
-              else { cm += (int)h2; digit = lane * 4 + 3; below = cm; cnt = (int)h3; } } }
-        }
-        const unsigned long long balm = __ballot(mine);
-        const int srcl = __ffsll((long long)balm) - 1;
-        digit = __shfl(digit, srcl, 64);
-        below = __shfl(below, srcl, 64);
-        cnt = __shfl(cnt, srcl, 64);
-        need -= below;
-        __builtin_amdgcn_wave_barrier();
-        if (cnt <= 64) {
-          // the bin's members into sel[] (the histogram is no longer needed), then exact ranks
-          int ns = 0;
-          visit([&](bool ok, float z, float omp) {
-            (void)omp;
-            const bool in = ok && z >= rlo && z <= rhi && min(255, (int)((z - rlo) * scale)) == digit;
-            const unsigned long long bal = __ballot(in);
-            if (in) sel[ns + __popcll(bal & ((1ull << lane) - 1ull))] = z;
-            ns += __popcll(bal);
-          });
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          const float key = (lane < ns) ? sel[lane] : kInf;
-          int rank = 0;
-          for (int q = 0; q < ns; ++q) { const float o = sel[q]; rank += (o < key || (o == key && q < lane)) ? 1 : 0; }
-          const unsigned long long balk = __ballot(lane < ns && rank == need - 1);
-          zk = __shfl(key, __ffsll((long long)balk) - 1, 64);
-          __builtin_amdgcn_wave_barrier();
-          break;
-        }
-        // narrow the range to the members of that bin
-        float nlo = kInf, nhi = -kInf;
-        visit([&](bool ok, float z, float omp) {
-          (void)omp;
-          if (ok && z >= rlo && z <= rhi && min(255, (int)((z - rlo) * scale)) == digit) { nlo = fminf(nlo, z); nhi = fmaxf(nhi, z); }
-        });
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { nlo = fminf(nlo, __shfl_xor(nlo, o, 64)); nhi = fmaxf(nhi, __shfl_xor(nhi, o, 64)); }
-        rlo = nlo; rhi = nhi;
-      }
-    }
-    // ---- one pass: product of the included factors, the nearest depth beyond the K-th, and the band population
-    // for kBandTries candidate half-widths (delta, delta/2, delta/4, ...)
-    constexpr int kBandTries = 6;
-    const float delta0 = (nc > K) ? kBandHalf * (zk - zmn) * (1.0f / (float)K) : 0.f;
-    float a = 1.0f, znext = kInf;
-    int cbs[kBandTries], cfs[kBandTries];
-#pragma unroll
-    for (int i = 0; i < kBandTries; ++i) { cbs[i] = 0; cfs[i] = 0; }
-    visit([&](bool ok, float z, float omp) {
-      if (ok) {
-        if (z <= zk) a *= omp; else znext = fminf(znext, z);
-        float dl = delta0;
-#pragma unroll
-        for (int i = 0; i < kBandTries; ++i) {
-          cbs[i] += (z > zk - dl && z <= zk + dl) ? 1 : 0;
-          cfs[i] += (z > zk + dl) ? 1 : 0;
-          dl *= 0.5f;
-        }
-      }
-    });
-    a = wave_prod(a);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      znext = fminf(znext, __shfl_xor(znext, o, 64));
-#pragma unroll
-      for (int i = 0; i < kBandTries; ++i) { cbs[i] += __shfl_xor(cbs[i], o, 64); cfs[i] += __shfl_xor(cfs[i], o, 64); }
-    }
-    // backward threshold: midway between the K-th and the (K+1)-th nearest depth
-    float zmid = zk;
-    if (nc > K && znext < kInf) {
-      zmid = 0.5f * (zk + znext);
-      if (!(zmid >= zk && zmid < znext)) zmid = zk;
-    }
-    // bounds for the next evaluations: lo < K-th <= hi, the band (lo, hi] sized to at most kBandFill candidates, so
-    // that the K nearest stay provable from counts while depths drift by up to the band's half-width
-    float blo = kInf, bhi = kInf;
-    if (nc > K) {
-      blo = bhi = zmid;
-      const int fill = band_fill;
-      float delta = delta0;
-      bool chosen = false;
-#pragma unroll
-      for (int i = 0; i < kBandTries; ++i) {
-        if (!chosen && cbs[i] <= fill && zk - delta < zk) {
-          blo = zk - delta; bhi = (cfs[i] == 0) ? kInf : zk + delta; chosen = true;
-        }
-        delta *= 0.5f;
-      }
-    }
-    if (lane == 0) {
-      const size_t pi = (size_t)gp;
-      const float sil = 1.0f - a;
-      if (sil_out) sil_out[pi] = sil;
-      float gx = 0.f, l = 0.f;
-      if (tsil) {
-        const float diff = sil - tsil[pi];
-        const int Bn = frame_window_size(n, M, window);
-        const float wn = w_sil / ((float)Bn * (float)S * (float)S);
-        l = fabsf(diff) * wn;
-        const float sgn = (diff > 0.f) ? 1.0f : ((diff < 0.f) ? -1.0f : 0.0f);
-        gx = -wn * sgn * a * (1.0f / kSigma);
-      }
-      gz[pi] = make_float2(gx, zmid);
-      zband[pi] = make_float2(blo, bhi);
-      lacc += (long long)(l * kLossFix);
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (qloss) {
-    if (lane == 0) wloss[w] = lacc;
-    __syncthreads();
-    if (t == 0) { long long tot = 0; for (int i = 0; i < kSelWaves; ++i) tot += wloss[i]; qloss[blockIdx.x] = tot; }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K5': colour render for visualisation (p3d_renderer.py:41-59,70-72: blur_radius 0, faces_per_pixel 1, HardPhongShader,
-// one point light at (0,0,3), constant vertex colour, white background).  Not on the optimisation path.
-//   vnormal_kernel      pytorch3d Meshes.verts_normals_packed (area-weighted incident face normals, normalised)
-//   color_zbuf_kernel   face-parallel z-buffer: (order-preserving depth key << 32 | face) with one 64-bit atomicMin
-//   color_shade_kernel  thread per pixel: screen-space barycentrics of the winning face, Phong terms
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-vnormal_kernel(ModelDev m, int M, const float* __restrict__ verts /*[M][3][Vp] world*/, float* __restrict__ vn /*[M][3][Vp]*/) {
-  const int v = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y, Vp = m.Vp;
-  if (v >= Vp) return;
-  const float* p = verts + (size_t)n * 3 * Vp;
-  float acc[3] = {0.f, 0.f, 0.f};
-  if (v < m.V) {
-    for (int i = m.vf_off[v]; i < m.vf_off[v + 1]; ++i) {
-      const int f = m.vf_idx[i] / 3;
-      const int i0 = m.faces[f * 3], i1 = m.faces[f * 3 + 1], i2 = m.faces[f * 3 + 2];
-      const float ux = p[i1] - p[i0], uy = p[Vp + i1] - p[Vp + i0], uz = p[2 * Vp + i1] - p[2 * Vp + i0];
-      const float wx = p[i2] - p[i0], wy = p[Vp + i2] - p[Vp + i0], wz = p[2 * Vp + i2] - p[2 * Vp + i0];
-      acc[0] += uy * wz - uz * wy; acc[1] += uz * wx - ux * wz; acc[2] += ux * wy - uy * wx;
-    }
-    const float inv = 1.0f / fmaxf(sqrtf(acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2]), 1e-6f);
-    acc[0] *= inv; acc[1] *= inv; acc[2] *= inv;
-  }
-#pragma unroll
-  for (int a = 0; a < 3; ++a) vn[((size_t)n * 3 + a) * Vp + v] = acc[a];
-}
-
-__global__ void __launch_bounds__(256)
-color_zbuf_kernel(ModelDev m, int S, const float* __restrict__ proj, unsigned long long* __restrict__ zbuf /*[M][S*S], preset to ~0*/) {
-  const int n = blockIdx.y, f = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15, Vp = m.Vp;
-  if (f >= m.F) return;
-  const float* px = proj + (size_t)n * 3 * Vp;
-  const int i0 = m.faces[f * 3], i1 = m.faces[f * 3 + 1], i2 = m.faces[f * 3 + 2];
-  const float ax = px[i0], ay = px[Vp + i0], az = px[2 * Vp + i0];
-  const float bx = px[i1], by = px[Vp + i1], bz = px[2 * Vp + i1];
-  const float cx = px[i2], cy = px[Vp + i2], cz = px[2 * Vp + i2];
-  FaceRec r;
-  if (!make_face_rec(ax, ay, az, bx, by, bz, cx, cy, cz, r)) return;
-  const float xlo = fminf(ax, fminf(bx, cx)), xhi = fmaxf(ax, fmaxf(bx, cx));
-  const float ylo = fminf(ay, fminf(by, cy)), yhi = fmaxf(ay, fmaxf(by, cy));
-  if (!(xlo == xlo && xhi == xhi && ylo == ylo && yhi == yhi) || xhi < -1.0f || xlo > 1.0f || yhi < -1.0f || ylo > 1.0f) return;
-  const float fs = (float)S;
-  const int c0 = (int)fminf(fmaxf(floorf(((1.0f - xhi) * fs - 1.0f) * 0.5f), 0.f), fs - 1.f);
-  const int c1 = (int)fminf(fmaxf(ceilf(((1.0f - xlo) * fs - 1.0f) * 0.5f), 0.f), fs - 1.f);
-  const int r0 = (int)fminf(fmaxf(floorf(((1.0f - yhi) * fs - 1.0f) * 0.5f), 0.f), fs - 1.f);
-  const int r1 = (int)fminf(fmaxf(ceilf(((1.0f - ylo) * fs - 1.0f) * 0.5f), 0.f), fs - 1.f);
-  const int bw = c1 - c0 + 1, npx = bw * (r1 - r0 + 1);
-  const float inv_s = 1.0f / fs;
-  unsigned long long* zb = zbuf + (size_t)n * S * S;
-  for (int q = sub; q < npx; q += 16) {
-    const int row = r0 + q / bw, col = c0 + q % bw;
-    PixEval e;
-    if (!face_pixel_eval(r, pix_to_ndc(col, inv_s), pix_to_ndc(row, inv_s), e) || !e.inside) continue;
-    atomicMin(&zb[row * S + col], ((unsigned long long)orderable(e.pz) << 32) | (unsigned)f);
-  }
-}
-
-__global__ void __launch_bounds__(256)
-color_shade_kernel(ModelDev m, int S, const float* __restrict__ proj, const float* __restrict__ verts /*[M][3][Vp] world*/,
-                   const float* __restrict__ vn, const unsigned long long* __restrict__ zbuf, float cr, float cg, float cb,
-                   float* __restrict__ image /*[M][3][S][S]*/) {
-  const int pix = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y, Vp = m.Vp;
-  if (pix >= S * S) return;
-  float rgb[3] = {1.0f, 1.0f, 1.0f};                       // BlendParams default background
-  const unsigned long long key = zbuf[(size_t)n * S * S + pix];
-  if (key != ~0ull) {
-    const int f = (int)(key & 0xffffffffull);
-    const int idx[3] = {m.faces[f * 3], m.faces[f * 3 + 1], m.faces[f * 3 + 2]};
-    const float* px = proj + (size_t)n * 3 * Vp;
-    FaceRec r;
-    make_face_rec(px[idx[0]], px[Vp + idx[0]], px[2 * Vp + idx[0]], px[idx[1]], px[Vp + idx[1]], px[2 * Vp + idx[1]],
-                  px[idx[2]], px[Vp + idx[2]], px[2 * Vp + idx[2]], r);
-    const float inv_s = 1.0f / (float)S;
-    const float dx = pix_to_ndc(pix % S, inv_s) - r.ax, dy = pix_to_ndc(pix / S, inv_s) - r.ay;
-    const float c1 = fmaf(dx, r.e1y, -(dy * r.e1x)), c2 = fmaf(dx, r.e2y, -(dy * r.e2x));
-    const float w[3] = {((c2 - c1) + r.area) * r.inv_den, -c2 * r.inv_den, c1 * r.inv_den};
-    const float* pw = verts + (size_t)n * 3 * Vp;
-    const float* pn = vn + (size_t)n * 3 * Vp;
-    float pos[3] = {0.f, 0.f, 0.f}, nr[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-      for (int a = 0; a < 3; ++a) { pos[a] = fmaf(w[k], pw[a * Vp + idx[k]], pos[a]); nr[a] = fmaf(w[k], pn[a * Vp + idx[k]], nr[a]); }
-    const float inn = 1.0f / fmaxf(sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]), 1e-6f);
-    nr[0] *= inn; nr[1] *= inn; nr[2] *= inn;
-    float ld[3] = {0.0f - pos[0], 0.0f - pos[1], 3.0f - pos[2]};           // PointLights(location = (0, 0, 3))
-    const float inl = 1.0f / fmaxf(sqrtf(ld[0] * ld[0] + ld[1] * ld[1] + ld[2] * ld[2]), 1e-6f);
-    ld[0] *= inl; ld[1] *= inl; ld[2] *= inl;
-    const float cosang = nr[0] * ld[0] + nr[1] * ld[1] + nr[2] * ld[2];
-    const float diffuse = 0.3f * fmaxf(cosang, 0.f);
-    float vd[3] = {0.0f - pos[0], 0.0f - pos[1], kCamDist - pos[2]};       // camera centre
-    const float inv_v = 1.0f / fmaxf(sqrtf(vd[0] * vd[0] + vd[1] * vd[1] + vd[2] * vd[2]), 1e-6f);
-    float va = 0.f;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) va += vd[a] * inv_v * (-ld[a] + 2.0f * cosang * nr[a]);
-    const float alpha = (cosang > 0.f) ? fmaxf(va, 0.f) : 0.f;
-    const float spec = 0.2f * powf(alpha, 64.0f);
-    const float amb = 0.5f + diffuse;
-    rgb[0] = amb * cr + spec; rgb[1] = amb * cg + spec; rgb[2] = amb * cb + spec;
-  }
-#pragma unroll
-  for (int a = 0; a < 3; ++a) image[((size_t)n * 3 + a) * S * S + pix] = rgb[a];
-}
-
-// gz = (dsil * (-(1 - sil) / sigma), zthr)   (component API: arbitrary upstream gradient)
-__global__ void gpix_from_dsil_kernel(size_t total, const float* __restrict__ sil, const float* __restrict__ dsil,
-                                      float2* __restrict__ gz) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < total) gz[i].x = -dsil[i] * (1.0f - sil[i]) * (1.0f / kSigma);
-}
-
-// 5e: backward, face-parallel gather (deterministic, no atomics).  16 lanes per face walk the face's pixel box
-// row-major like the forward sweep; d(signed dist^2)/d(vertex) flows through the nearest edge only.
-__global__ void __launch_bounds__(256)
-raster_bwd_kernel(int F, int S, const float4* __restrict__ frec, const float* __restrict__ zc, const float2* __restrict__ gz,
-                  float* __restrict__ dface /*[M][F][6]*/) {
-  const int n = blockIdx.y;
-  const int f = blockIdx.x * 16 + (threadIdx.x >> 4);
-  const int sub = threadIdx.x & 15;
-  float ga[2] = {0.f, 0.f}, gb[2] = {0.f, 0.f}, gc[2] = {0.f, 0.f};
-  if (f < F) {
-    FaceRec r;
-    int2 box;
-    load_face_rec(frec + ((size_t)n * F + f) * 3, r, box);
-    const int c0 = box.x & 0xffff, c1 = box.x >> 16, r0 = box.y & 0xffff, r1 = box.y >> 16;
-    if (c0 <= c1) {
-      const float inv_s = 1.0f / (float)S;
-      const float zcn = zc[n];
-      const float2* gp = gz + (size_t)n * S * S;
-      const int bw = c1 - c0 + 1, npx = bw * (r1 - r0 + 1);
-      const int srow = 16 / bw, scol = 16 - srow * bw;
-      int ry = sub / bw, cx = sub - ry * bw;
-      for (int q = sub; q < npx; q += 16) {
-        {
-          const int row = r0 + ry, col = c0 + cx;
-          cx += scol; ry += srow;
-          if (cx >= bw) { cx -= bw; ++ry; }
-          const float2 g = gp[row * S + col];
-          if (g.x == 0.f) continue;
-          PixEval e;
-          if (!face_pixel_eval(r, pix_to_ndc(col, inv_s), pix_to_ndc(row, inv_s), e)) continue;
-          if (e.pz - zcn > g.y) continue;           // not among the pixel's K nearest
-          // dL/dd = gpix * p ;  d = -+dist ;  d dist/d(u) = -2 q (1 - tc), d dist/d(w) = -2 q tc
-          const float gd = g.x * prob_fast(e.d) * (e.inside ? -1.0f : 1.0f) * -2.0f;
-          const float ku = 1.0f - e.tc, kw = e.tc;
-          const float ca = (e.edge == 2) ? 0.f : ku;
-          const float cb = (e.edge == 0) ? kw : ((e.edge == 2) ? ku : 0.f);
-          const float cc = (e.edge == 0) ? 0.f : kw;
-          const float gx = gd * e.qx, gy = gd * e.qy;
-          ga[0] = fmaf(ca, gx, ga[0]); ga[1] = fmaf(ca, gy, ga[1]);
-          gb[0] = fmaf(cb, gx, gb[0]); gb[1] = fmaf(cb, gy, gb[1]);
-          gc[0] = fmaf(cc, gx, gc[0]); gc[1] = fmaf(cc, gy, gc[1]);
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) {
-    ga[0] += __shfl_xor(ga[0], o, 64); ga[1] += __shfl_xor(ga[1], o, 64);
-    gb[0] += __shfl_xor(gb[0], o, 64); gb[1] += __shfl_xor(gb[1], o, 64);
-    gc[0] += __shfl_xor(gc[0], o, 64); gc[1] += __shfl_xor(gc[1], o, 64);
-  }
-  if (f < F && sub == 0) {
-    float* o = dface + ((size_t)n * F + f) * 6;
-    o[0] = ga[0]; o[1] = ga[1]; o[2] = gb[0]; o[3] = gb[1]; o[4] = gc[0]; o[5] = gc[1];
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K6: vertex adjoint: gather raster grads of incident faces, camera adjoint, joint-regressor adjoint,
-//     skinning adjoint wrt v_posed.   block = 256 vertices x FRB frames
-// ------------------------------------------------------------------------------------------------
-template <int FRB>
-__global__ void __launch_bounds__(256)
-vertex_bwd_kernel(ModelDev m, int M, const float* __restrict__ proj, const float* __restrict__ dface,
-                  const float* __restrict__ dJ41 /*[M][41][3] or null*/,
-                  const float* __restrict__ dverts_ext /*[M][3][Vp] extra world-space adjoint or null*/,
-                  const float* __restrict__ Am, float* __restrict__ dvert /*[M][3][Vp]*/,
-                  float* __restrict__ dvp /*[M][3][Vp]*/, float* __restrict__ dtr_part /*[VT][M][3]*/) {
-  __shared__ float As[FRB][420];
-  __shared__ float dJs[FRB][123];
-  __shared__ float red[16];
-  const int Vp = m.Vp;
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  const int n0 = blockIdx.y * FRB;
-  for (int i = threadIdx.x; i < FRB * 420; i += 256) {
-    const int f = i / 420;
-    As[f][i % 420] = (n0 + f < M) ? Am[(size_t)(n0 + f) * 420 + (i % 420)] : 0.f;
-  }
-  for (int i = threadIdx.x; i < FRB * 123; i += 256) {
-    const int f = i / 123;
-    dJs[f][i % 123] = (dJ41 && n0 + f < M) ? dJ41[(size_t)(n0 + f) * 123 + (i % 123)] : 0.f;
-  }
-  __syncthreads();
-  int lm = -1;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) if (v == m.landmarks[i]) lm = i;
-  const bool live = v < m.V;
-  for (int f = 0; f < FRB; ++f) {
-    const int n = n0 + f;
-    if (n >= M) break;
-    float g[3] = {0.f, 0.f, 0.f};       // adjoint of translated world vertex (raster path)
-    if (live && dface) {
-      float gxn = 0.f, gyn = 0.f;
-      const float* df = dface + (size_t)n * m.F * 6;
-      for (int i = m.vf_off[v]; i < m.vf_off[v + 1]; ++i) {
-        const int fc = m.vf_idx[i];                  // face*3 + corner
-        gxn += df[fc * 2];
-        gyn += df[fc * 2 + 1];
-      }
-      const float* pv = proj + (size_t)n * 3 * Vp;
-      world_to_ndc_bwd(pv[v], pv[Vp + v], pv[2 * Vp + v], gxn, gyn, g[0], g[1], g[2]);
-    }
-    if (live && dverts_ext) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) g[a] += dverts_ext[((size_t)n * 3 + a) * Vp + v];
-    }
-    // translation adjoint: sum over vertices of the translated-vertex adjoint
-    {
-      const float s0 = wave_sum(live ? g[0] : 0.f), s1 = wave_sum(live ? g[1] : 0.f), s2 = wave_sum(live ? g[2] : 0.f);
-      __syncthreads();                               // red[] of the previous frame has been consumed
-      if ((threadIdx.x & 63) == 0) { float* q = &red[(threadIdx.x >> 6) * 4]; q[0] = s0; q[1] = s1; q[2] = s2; }
-      __syncthreads();
-      if (threadIdx.x < 3)
-        dtr_part[((size_t)blockIdx.x * M + n) * 3 + threadIdx.x] =
-            ((red[threadIdx.x] + red[4 + threadIdx.x]) + red[8 + threadIdx.x]) + red[12 + threadIdx.x];
-    }
-    // joints = J_regressor^T verts  (+ landmark picks)
-    float dv[3] = {g[0], g[1], g[2]};
-    if (live) {
-      for (int e = 0; e < m.Kj; ++e) {
-        const int j = m.jrv_j[e * Vp + v];
-        const float c = m.jrv_val[e * Vp + v];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) dv[a] = fmaf(c, dJs[f][j * 3 + a], dv[a]);
-      }
-      if (lm >= 0) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) dv[a] += dJs[f][(35 + lm) * 3 + a];
-      }
-    }
-    // skinning: vert = T.R vp + T.t  ->  dvp = T.R^T dv
-    float T[9];
-#pragma unroll
-    for (int e = 0; e < 9; ++e) T[e] = 0.f;
-    if (live) {
-      for (int e = 0; e < m.Kw; ++e) {
-        const int j = m.w_j[e * Vp + v];
-        const float wv = m.w_val[e * Vp + v];
-        const float* A = &As[f][j * 12];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int b = 0; b < 3; ++b) T[a * 3 + b] = fmaf(wv, A[a * 4 + b], T[a * 3 + b]);
-      }
-    }
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      const float o = T[b] * dv[0] + T[3 + b] * dv[1] + T[6 + b] * dv[2];
-      if (v < Vp) {
-        dvp[((size_t)n * 3 + b) * Vp + v] = live ? o : 0.f;
-        dvert[((size_t)n * 3 + b) * Vp + v] = live ? dv[b] : 0.f;
-      }
-    }
-  }
-}
-
-// K7: dA[n][j] = sum over the skin-weight column of joint j of  w * dvert (x) [v_posed; 1]
-__device__ __forceinline__ void
-dA_block(const ModelDev& m, int j, int n, const float* __restrict__ dvert, const float* __restrict__ vposed,
-         float* __restrict__ dA /*[M][35][12]*/, float (*part)[32]) {
-  const int Vp = m.Vp;
-  const float* dv = dvert + (size_t)n * 3 * Vp;
-  const float* vp = vposed + (size_t)n * 3 * Vp;
-  float acc[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  for (int i = m.wc_off[j] + threadIdx.x; i < m.wc_off[j + 1]; i += 256) {
-    const int v = m.wc_v[i];
-    const float wv = m.wc_val[i];
-    const float p[4] = {vp[v], vp[Vp + v], vp[2 * Vp + v], 1.0f};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float d = wv * dv[a * Vp + v];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a * 4 + b] = fmaf(d, p[b], acc[a * 4 + b]);
-    }
-  }
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const float tot = wave_sums<16>(acc, lane);           // value lane >> 2
-  if ((lane & 3) == 0) part[w][lane >> 2] = tot;
-  __syncthreads();
-  if (threadIdx.x < 12)
-    dA[((size_t)n * 35 + j) * 12 + threadIdx.x] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
-}
-
-// K8: pose-blend adjoint  dpf[n][k] = sum_col dvp[n][col] * pd[k][col]   (split over columns)
-// one wave = 16 frames x 8 pose features, lanes stride the 3*Vp columns of its column split.
-constexpr int PB_NT = 8, PB_KT = 8;
-constexpr int kAsmElem = 4, kAsmLoss = 16;   // assemble_kernel: blocks for element-wise gradients / loss partial sums
-// one wave: PB_NT frames x PB_KT pose features over one column split
-__device__ __forceinline__ void
-poseblend_bwd_wave(const ModelDev& m, int M, int CS, int kx, int ny, int cs, int lane, const float* __restrict__ dvp,
-                   float* __restrict__ dpf_part /*[CS][M][308]*/) {
-  const int k0 = kx * PB_KT, n0 = ny * PB_NT;
-  const int ncol = 3 * m.Vp;
-  const int chunk = ((ncol / 64 + CS - 1) / CS) * 64;
-  const int cbeg = cs * chunk, cend = min(ncol, cbeg + chunk);
-  float acc[PB_NT * PB_KT];
-#pragma unroll
-  for (int i = 0; i < PB_NT * PB_KT; ++i) acc[i] = 0.f;
-  float p[PB_KT], d[PB_NT];
-  auto fetch = [&](int c, float* pp, float* dd) {
-#pragma unroll
-    for (int k = 0; k < PB_KT; ++k) pp[k] = (k0 + k < 306 && c < cend) ? m.pd[(size_t)(k0 + k) * ncol + c] : 0.f;
-#pragma unroll
-    for (int i = 0; i < PB_NT; ++i) dd[i] = (n0 + i < M && c < cend) ? dvp[(size_t)(n0 + i) * ncol + c] : 0.f;
-  };
-  fetch(cbeg + lane, p, d);
-  for (int c = cbeg + lane; c < cend; c += 64) {
-    float pn[PB_KT], dn[PB_NT];
-    fetch(c + 64, pn, dn);                 // next columns in flight while this block of FMAs issues
-#pragma unroll
-    for (int i = 0; i < PB_NT; ++i)
-#pragma unroll
-      for (int k = 0; k < PB_KT; ++k) acc[i * PB_KT + k] = fmaf(d[i], p[k], acc[i * PB_KT + k]);
-#pragma unroll
-    for (int k = 0; k < PB_KT; ++k) p[k] = pn[k];
-#pragma unroll
-    for (int i = 0; i < PB_NT; ++i) d[i] = dn[i];
-  }
-  static_assert(PB_NT * PB_KT == 64 || PB_NT * PB_KT == 128, "fold sequence below assumes 64 or 128 accumulators");
-  constexpr int NACC = PB_NT * PB_KT;
-  fold_accumulators<NACC / 2>(acc, lane, 32);
-  fold_accumulators<NACC / 4>(acc, lane, 16);
-  fold_accumulators<NACC / 8>(acc, lane, 8);
-  fold_accumulators<NACC / 16>(acc, lane, 4);
-  fold_accumulators<NACC / 32>(acc, lane, 2);
-  fold_accumulators<NACC / 64>(acc, lane, 1);
-  // every lane now holds the wave-wide sums of accumulators lane * (NACC/64) + r
-#pragma unroll
-  for (int r = 0; r < NACC / 64; ++r) {
-    const int e = (NACC / 64) * lane + r, i = e / PB_KT, k = e % PB_KT;
-    if (n0 + i < M && k0 + k < 306) dpf_part[((size_t)cs * M + n0 + i) * 308 + k0 + k] = acc[r];
-  }
-}
-
-// K9: shape-blend adjoint.  shared betas: dbeta_part[block][b] = sum_col sd[b][col] * sum_n dvp[n][col]
-//     per-frame betas (blockIdx.y = frame): no sum over frames.
-__device__ __forceinline__ void
-dbeta_block(const ModelDev& m, int M, int nb, int shared, int bx, int by, int bz, int gx, int gzn,
-            const float* __restrict__ dvp, float* __restrict__ dbeta_part /*[nbs][gzn * gx][nb]*/, float (*part)[32]) {
-  const int ncol = 3 * m.Vp;
-  const int c = bx * 256 + threadIdx.x;
-  float g = 0.f;
-  if (c < ncol) {
-    if (shared) {       // frames are split over bz
-      const int per = (M + gzn - 1) / gzn;
-      const int n0 = bz * per, n1 = min(M, n0 + per);
-      for (int n = n0; n < n1; ++n) g += dvp[(size_t)n * ncol + c];
-    } else {
-      g = dvp[(size_t)by * ncol + c];
-    }
-  }
-  const size_t pidx = (size_t)by * gzn * gx + (size_t)bz * gx + bx;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int b0 = 0; b0 < nb; b0 += 32) {                 // shape directions in groups of 32
-    float val[32];
-#pragma unroll
-    for (int b = 0; b < 32; ++b) val[b] = (c < ncol && b0 + b < nb) ? g * m.sd[(size_t)(b0 + b) * ncol + c] : 0.f;
-    const float tot = wave_sums<32>(val, lane);         // value lane >> 1
-    __syncthreads();
-    if ((lane & 1) == 0) part[w][lane >> 1] = tot;
-    __syncthreads();
-    if (threadIdx.x < 32 && b0 + threadIdx.x < nb)
-      dbeta_part[pidx * nb + b0 + threadIdx.x] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
-  }
-}
-
-// pose-blend adjoint on the matrix cores:  dpf[n][k] = sum_c dvp[n][c] * pd[k][c]  (c: the 3 Vp columns).
-// A block owns 16 frames x 32 pose features and one of PBM_SPLITS column ranges; its four waves take a quarter of
-// the range each and their tiles are added through LDS in a fixed order.  Both operands are rows of length 3 Vp, so
-// a lane fetches FOUR consecutive columns (one 16-byte load; 16 rows x 64 bytes per instruction) and the four
-// v_mfma_f32_16x16x4_f32 that follow pair component i of A with component i of B: the instruction only needs A and B
-// to agree on which column sits in which k slot.
-#ifndef SMALFIT_PBM_SPLITS
-#define SMALFIT_PBM_SPLITS 6
-#endif
-constexpr int PBM_SPLITS = SMALFIT_PBM_SPLITS, PBM_U = 4;
-__device__ __forceinline__ void
-poseblend_bwd_mfma_block(const ModelDev& m, int M, int ftile, int kpair, int split, const float* __restrict__ dvp,
-                         float* __restrict__ dpf_part /*[PBM_SPLITS][M][308]*/, float (*red)[8][64]) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int ncol = 3 * m.Vp, nsteps = ncol / 16;            // Vp is a multiple of 64
-  const int per = (nsteps + PBM_SPLITS * 4 - 1) / (PBM_SPLITS * 4);
-  const int s_beg = (split * 4 + w) * per, s_end = min(nsteps, s_beg + per);
-  const int n0 = ftile * 16, k0 = kpair * 32;
-  const int row = lane & 15, cq = (lane >> 4) * 4;
-  const float4* pa = reinterpret_cast<const float4*>(dvp + (size_t)min(n0 + row, M - 1) * ncol + cq);
-  const float4* pb0 = reinterpret_cast<const float4*>(m.pd + (size_t)min(k0 + row, 305) * ncol + cq);
-  const float4* pb1 = reinterpret_cast<const float4*>(m.pd + (size_t)min(k0 + 16 + row, 305) * ncol + cq);
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-  float4 xa[PBM_U], x0[PBM_U], x1[PBM_U], ya[PBM_U], y0[PBM_U], y1[PBM_U];
-  auto load_batch = [&](int st0, float4* A, float4* B0, float4* B1) {
-#pragma unroll
-    for (int u = 0; u < PBM_U; ++u) {
-      const int st = min(st0 + u, nsteps - 1);               // past the end: a valid address, zeroed below
-      A[u] = pa[st * 4]; B0[u] = pb0[st * 4]; B1[u] = pb1[st * 4];
-      if (st0 + u >= s_end) A[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto mfma_batch = [&](const float4* A, const float4* B0, const float4* B1) {
-#pragma unroll
-    for (int u = 0; u < PBM_U; ++u) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u].x, B0[u].x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u].x, B1[u].x, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u].y, B0[u].y, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u].y, B1[u].y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u].z, B0[u].z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u].z, B1[u].z, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u].w, B0[u].w, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u].w, B1[u].w, acc1, 0, 0, 0);
-    }
-  };
-  load_batch(s_beg, xa, x0, x1);
-  for (int st = s_beg; st < s_end; st += 2 * PBM_U) {
-    load_batch(st + PBM_U, ya, y0, y1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_batch(xa, x0, x1);
-    __builtin_amdgcn_sched_barrier(0);
-    load_batch(st + 2 * PBM_U, xa, x0, x1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_batch(ya, y0, y1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) { red[w][r][lane] = acc0[r]; red[w][4 + r][lane] = acc1[r]; }
-  __syncthreads();
-  // D[row = 4 (lane >> 4) + r][col = lane & 15]; wave t finishes registers 2t, 2t+1 of the eight
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int reg = w * 2 + q, r = reg & 3, tile = reg >> 2;
-    const float tot = ((red[0][reg][lane] + red[1][reg][lane]) + red[2][reg][lane]) + red[3][reg][lane];
-    const int n = n0 + 4 * (lane >> 4) + r, k = k0 + tile * 16 + (lane & 15);
-    if (n < M && k < 306) dpf_part[((size_t)split * M + n) * 308 + k] = tot;
-  }
-}
-
-// everything between the vertex adjoint and the chain adjoint in ONE launch (the three parts are independent and
-// each is latency-bound on its own): blocks [0, nPB) pose-blend adjoint (4 waves = 4 tiles), then 35 x M blocks
-// dA_j, then the shape-blend adjoint partials.
-__global__ void __launch_bounds__(256)
-lbs_bwd_mid_kernel(ModelDev m, int M, int CS, int nb, int betas_shared, int nPB, int nDB_x, int nDB_y, int nDB_z,
-                   const float* __restrict__ dvert, const float* __restrict__ vposed, const float* __restrict__ dvp,
-                   float* __restrict__ dA, float* __restrict__ dpf_part, float* __restrict__ dbeta_part) {
-  __shared__ float part[4][32];
-  __shared__ float tile_red[4][8][64];
-  int blk = blockIdx.x;
-  if (blk < nPB) {
-    const int nft = (M + 15) / 16;
-    poseblend_bwd_mfma_block(m, M, blk % nft, (blk / nft) % 10, blk / (nft * 10), dvp, dpf_part, tile_red);
-    return;
-  }
-  blk -= nPB;
-  if (blk < 35 * M) { dA_block(m, blk % 35, blk / 35, dvert, vposed, dA, part); return; }
-  blk -= 35 * M;
-  if (blk < nDB_x * nDB_y * nDB_z)
-    dbeta_block(m, M, nb, betas_shared, blk % nDB_x, (blk / nDB_x) % nDB_y, blk / (nDB_x * nDB_y), nDB_x, nDB_z, dvp, dbeta_part, part);
-}
-
-// ------------------------------------------------------------------------------------------------
-// K10: per-frame chain adjoint: dA, dpf -> d theta, d logscale, d rest joints
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-chain_bwd_kernel(ModelDev m, int M, const float* __restrict__ theta, const float* __restrict__ Rm,
-                 const float* __restrict__ Gm, const float* __restrict__ scm,
-                 const float* __restrict__ Jrest, int j_stride, const float* __restrict__ dA,
-                 const float* __restrict__ dpf_part, int CS, const float* __restrict__ dth_direct,
-                 float* __restrict__ dtheta /*[M][105]*/, float* __restrict__ dls /*[M][6]*/,
-                 float* __restrict__ dJrest /*[M][105]*/, float* __restrict__ dbetaJ /*[M][NBall] or null*/) {
-  // One block per frame: 256 threads for the loads / reductions at either end (latency), the first wave walks the
-  // tree.  The tree is walked by depth (TreeLevels), 12 lanes per joint of the level.  Every joint
-  // writes what it owes its parent into its own slots (cG, cJ, cS) and parents gather from their children in
-  // descending joint order, so no two lanes ever add into the same word (deterministic).
-  __shared__ float R[35][9], G[35][12], sc[35][3], J[35][3];
-  __shared__ float dG[35][12], dR[35][9], dJ[35][3];
-  __shared__ float cG[35][12], cJ[35][3], cS[35][3], sOwn[35][3];
-  __shared__ float dRp[35][9], djv[35][3];
-  __shared__ int sidx[105];
-  __shared__ float psum[4][320];
-  __shared__ float isc[35][3];          // 1 / s_j[a]
-  __shared__ float sJS[105 * 48];       // d(rest joints)/d(beta), staged while the tree is walked
-  __shared__ unsigned char t_lvl_off[36], t_lvl_joint[36], t_child_off[36], t_child_idx[36], t_par[36];
-  const int n = blockIdx.x, l = threadIdx.x;
-  const TreeLevels& tl = m.tree;
-  if (l < 36) {
-    t_lvl_off[l] = tl.lvl_off[l]; t_child_off[l] = tl.child_off[l];
-    if (l < 35) { t_lvl_joint[l] = tl.lvl_joint[l]; t_child_idx[l] = tl.child_idx[l]; t_par[l] = (unsigned char)max(m.parents[l], 0); }
-  }
-  const int nlev = tl.nlev;
-  const bool js_lds = dbetaJ && m.NBall <= 48;
-  if (js_lds) for (int i = l; i < 105 * m.NBall; i += 256) sJS[i] = m.JS[i];
-  for (int i = l; i < 315; i += 256) R[i / 9][i % 9] = Rm[(size_t)n * 315 + i];
-  for (int i = l; i < 420; i += 256) G[i / 12][i % 12] = Gm[(size_t)n * 420 + i];
-  for (int i = l; i < 105; i += 256) {
-    { const float sv = scm[(size_t)n * 105 + i]; sc[i / 3][i % 3] = sv; isc[i / 3][i % 3] = 1.0f / sv; }
-    J[i / 3][i % 3] = Jrest[(size_t)n * j_stride + i];
-    sOwn[i / 3][i % 3] = 0.f; cS[i / 3][i % 3] = 0.f; cJ[i / 3][i % 3] = 0.f;
-    sidx[i] = m.scale_idx[i];
-  }
-  // pose-feature adjoint -> dR of joints 1..34: sum of the column-split partials in a fixed order (four quarters of
-  // the splits in parallel, then the quarters); root starts at 0
-  if (dpf_part) {
-    const int per = (CS + 3) / 4, q = l >> 6, c0 = q * per, c1 = min(CS, c0 + per);
-    const size_t stride = (size_t)M * 308;
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
-      const int el = (l & 63) + 64 * r;
-      if (el < 306) {
-        const float* src = dpf_part + (size_t)n * 308 + el;
-        float sacc = 0.f;
-        if (c1 - c0 == 4) {                      // the usual case: four independent loads in flight
-          const float v0 = src[c0 * stride], v1 = src[(c0 + 1) * stride], v2 = src[(c0 + 2) * stride], v3 = src[(c0 + 3) * stride];
-          sacc = ((v0 + v1) + v2) + v3;
-        } else {
-          for (int c = c0; c < c1; ++c) sacc += src[c * stride];
-        }
-        psum[q][el] = sacc;
-      }
-    }
-  }
-  __syncthreads();
-  for (int i = l; i < 315; i += 256)
-    dR[i / 9][i % 9] = (i >= 9 && dpf_part) ? ((psum[0][i - 9] + psum[1][i - 9]) + psum[2][i - 9]) + psum[3][i - 9] : 0.f;
-  // A_j = [G.R | G.t - G.R J_j]
-  for (int i = l; i < 420; i += 256) {
-    const int j = i / 12, e = i % 12, a = e >> 2, b = e & 3;
-    const float* da = dA + ((size_t)n * 35 + j) * 12;
-    dG[j][e] = (b < 3) ? da[e] - da[a * 4 + 3] * J[j][b] : da[e];
-  }
-  for (int i = l; i < 105; i += 256) {
-    const int j = i / 3, c = i % 3;
-    const float* da = dA + ((size_t)n * 35 + j) * 12;
-    dJ[j][c] = -(G[j][0 * 4 + c] * da[3] + G[j][1 * 4 + c] * da[7] + G[j][2 * 4 + c] * da[11]);
-  }
-  __syncthreads();
-  const int slot = l / 12, e = l % 12;
-  if (l < 64)   // the walk needs 60 lanes: one wave, no block barriers (LDS operations of a wave complete in order)
-  for (int L = nlev - 1; L >= 1; --L) {
-    const int j0 = t_lvl_off[L], nj = t_lvl_off[L + 1] - j0;
-    for (int base = 0; base < nj; base += 5) {           // 5 joints x 12 lanes per pass
-      const bool live = (slot < 5) && (base + slot < nj);
-      const int i = live ? t_lvl_joint[j0 + base + slot] : 0;
-      const int p = live ? t_par[i] : 0;
-      // gather what the children owe this joint's dG (children were finished one level deeper)
-      if (live) {
-        float acc = dG[i][e];
-        for (int q = t_child_off[i]; q < t_child_off[i + 1]; ++q) acc += cG[t_child_idx[q]][e];
-        dG[i][e] = acc;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      // dR' = G_p.R^T dG_i.R ; dj = G_p.R^T dG_i.t
-      if (live) {
-        if (e < 9) {
-          const int a = e / 3, b = e % 3;
-          dRp[i][e] = G[p][0 * 4 + a] * dG[i][0 * 4 + b] + G[p][1 * 4 + a] * dG[i][1 * 4 + b] + G[p][2 * 4 + a] * dG[i][2 * 4 + b];
-        } else {
-          const int a = e - 9;
-          djv[i][a] = G[p][0 * 4 + a] * dG[i][3] + G[p][1 * 4 + a] * dG[i][7] + G[p][2 * 4 + a] * dG[i][11];
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      if (live) {
-        if (e < 9) {
-          const int a = e / 3, c = e % 3;
-          // owed to dG_p.R[a][c]: sum_b dG_i.R[a][b] R'[c][b] + dG_i.t[a] (J_i - J_p)[c]
-          float acc = dG[i][a * 4 + 3] * (J[i][c] - J[p][c]);
-#pragma unroll
-          for (int b = 0; b < 3; ++b) acc = fmaf(dG[i][a * 4 + b], R[i][c * 3 + b] * sc[i][b] * isc[p][c], acc);
-          cG[i][a * 4 + c] = acc;
-          // dR_i[a][c] += dR'[a][c] s_i[c] / s_p[a]
-          dR[i][a * 3 + c] += dRp[i][a * 3 + c] * sc[i][c] * isc[p][a];
-        } else {
-          const int a = e - 9;
-          cG[i][a * 4 + 3] = dG[i][a * 4 + 3];
-          cJ[i][a] = djv[i][a];                          // dJ_i += dj, dJ_p -= dj (applied after the walk)
-          {                                              // ds_i[b] += sum_a dR'[a][b] R_i[a][b] / s_p[a]   (b = a here)
-            const int b = a;
-            float acc = 0.f;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) acc = fmaf(dRp[i][r * 3 + b], R[i][r * 3 + b] * isc[p][r], acc);
-            sOwn[i][b] = acc;
-          }
-          {                                              // ds_p[a] -= sum_b dR'[a][b] R'[a][b] / s_p[a]
-            float acc = 0.f;
-#pragma unroll
-            for (int b = 0; b < 3; ++b) acc = fmaf(dRp[i][a * 3 + b], R[i][a * 3 + b] * sc[i][b] * isc[p][a], acc);
-            cS[i][a] = acc * isc[p][a];
-          }
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-  __syncthreads();
-  // root: gather its children, then its own rotation / joint adjoint
-  if (l < 12) {
-    float acc = dG[0][l];
-    for (int q = t_child_off[0]; q < t_child_off[1]; ++q) acc += cG[t_child_idx[q]][l];
-    dG[0][l] = acc;
-  }
-  __syncthreads();
-  if (l < 9) dR[0][l] += dG[0][(l / 3) * 4 + (l % 3)];
-  // joint and scale adjoints: children first (descending), then the joint's own term -- the order of a reverse loop
-  for (int i = l; i < 105; i += 256) {
-    const int j = i / 3, a = i % 3;
-    float aj = dJ[j][a], as = 0.f;
-    for (int q = t_child_off[j]; q < t_child_off[j + 1]; ++q) { aj -= cJ[t_child_idx[q]][a]; as -= cS[t_child_idx[q]][a]; }
-    if (j > 0) { aj += cJ[j][a]; as += sOwn[j][a]; }
-    else aj += dG[0][a * 4 + 3];
-    dJ[j][a] = aj;
-    sOwn[j][a] = as;                                      // now the full d loss / d s_j[a]
-  }
-  __syncthreads();
-  if (l < 35) {
-    const float th[3] = {theta[(n * 35 + l) * 3], theta[(n * 35 + l) * 3 + 1], theta[(n * 35 + l) * 3 + 2]};
-    float g[9], d[3];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) g[q] = dR[l][q];
-    rodrigues_bwd(th, g, d);
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-      dtheta[(size_t)n * 105 + l * 3 + a] = d[a] + (dth_direct ? dth_direct[(size_t)n * 105 + l * 3 + a] : 0.f);
-  }
-  if (dls) {                                     // d log-scale: 6 masked sums over the 105 (joint, axis) scales
-    const int w = l >> 6, lane = l & 63;
-    for (int sidx_l = w; sidx_l < 6; sidx_l += 4) {
-      float v = 0.f;
-      if (sidx[lane] == sidx_l) v = sOwn[lane / 3][lane % 3] * sc[lane / 3][lane % 3];
-      if (lane + 64 < 105 && sidx[lane + 64] == sidx_l) v += sOwn[(lane + 64) / 3][(lane + 64) % 3] * sc[(lane + 64) / 3][(lane + 64) % 3];
-      v = wave_sum(v);
-      if (lane == 0) dls[(size_t)n * 6 + sidx_l] = v;
-    }
-  }
-  for (int i = l; i < 105; i += 256) dJrest[(size_t)n * 105 + i] = dJ[i / 3][i % 3];
-  // rest joints are affine
-  if (dbetaJ) {
-    const int w = l >> 6, b = l & 63;
-    if (b < m.NBall) {
-      float acc = 0.f;
-      if (js_lds) {
-#pragma unroll 9
-        for (int r = 0; r < 27; ++r) { const int i = w * 27 + r; if (i < 105) acc = fmaf(dJ[i / 3][i % 3], sJS[i * m.NBall + b], acc); }
-      } else {
-        for (int i = w * 27; i < min(105, w * 27 + 27); ++i) acc = fmaf(dJ[i / 3][i % 3], m.JS[i * m.NBall + b], acc);
-      }
-      psum[w][b] = acc;
-    }
-    __syncthreads();
-    if (l < m.NBall) dbetaJ[(size_t)n * m.NBall + l] = ((psum[0][l] + psum[1][l]) + psum[2][l]) + psum[3][l];
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K11: gradient assembly (single block): shared-parameter reductions, masks, loss totals
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-assemble_kernel(AssembleArgs a) {
-  // Blocks take roles (kAsmElem / kAsmLoss are compile-time):
-  //   [0, nbs)            d loss / d betas of shape set s: column-block partials + joint path + prior
-  //   nbs                 limb scales
-  //   next kAsmElem       rotations / translation: masks, vertex-block partials
-  //   next kAsmLoss       partial sums of the silhouette loss
-  // and the block that finishes last adds up the eight loss terms (fixed order: deterministic).
-  __shared__ float red[16];
-  __shared__ float bsum[12][64];
-  __shared__ float part[32][8];
-  __shared__ int is_last;
-  const int t = threadIdx.x;
-  const int M = a.M;
-  const int nbs = a.betas_shared ? 1 : M;
-  int role = blockIdx.x;
-  if (role < nbs) {
-    if (a.g_betas) {
-      const int s = role;
-      const int b = t % 20, slice = t / 20;
-      if (slice < 12 && b < a.nb) {
-        float acc = 0.f;
-        const int nlo = a.betas_shared ? 0 : s, nhi = a.betas_shared ? M : s + 1;
-        for (int n = nlo + slice; n < nhi; n += 12) acc += a.dbetaJ[(size_t)n * a.NBall + b];
-        const int nparts = a.nblk_beta * a.ngrp_beta;
-        for (int blk = slice; blk < nparts; blk += 12) acc += a.dbeta_part[((size_t)s * nparts + blk) * a.nb + b];
-        bsum[slice][b] = acc;
-      }
-      __syncthreads();
-      if (t < a.nb) {
-        float tot = 0.f;
-        for (int sl = 0; sl < 12; ++sl) tot += bsum[sl][t];
-        if (a.gb_prior && s == 0) tot += a.gb_prior[t];
-        a.g_betas[s * a.nb + t] = tot;
-      }
-    }
-  } else if ((role -= nbs) == 0) {
-    if (a.g_ls) {
-      if (a.ls_shared) {
-        // 6 scales x 32 frame slices
-        const int e = t & 7, sl = t >> 3;
-        float acc = 0.f;
-        if (e < 6) for (int n = sl; n < M; n += 32) acc += a.dls[(size_t)n * 6 + e];
-        part[sl][e] = acc;                 // then the 32 slices of each scale in a fixed order
-        __syncthreads();
-        if (t < 6) {
-          float tot = 0.f;
-          for (int i = 0; i < 32; ++i) tot += part[i][t];
-          if (a.gls_prior) tot += a.gls_prior[t];
-          a.g_ls[t] = tot;
-        }
-      } else {
-        for (int i = t; i < M * 6; i += 256) a.g_ls[i] = a.dls[i];
-      }
-    }
-  } else if ((role -= 1) < kAsmElem) {
-    const int gt = role * 256 + t, gs = kAsmElem * 256;
-    for (int i = gt; i < M * 3; i += gs) {
-      const int n = i / 3, e = i % 3;
-      if (a.g_grot) a.g_grot[i] = a.dtheta[(size_t)n * 105 + e] * a.gmask[e];
-      if (a.g_trans) {
-        float acc = a.dtr_direct ? a.dtr_direct[i] : 0.f;
-        for (int vt = 0; vt < a.nvt; ++vt) acc += a.dtr_part[((size_t)vt * M + n) * 3 + e];
-        a.g_trans[i] = acc;
-      }
-    }
-    if (a.g_jrot)
-      for (int i = gt; i < M * 102; i += gs) {
-        const int n = i / 102, e = i % 102;
-        a.g_jrot[i] = a.dtheta[(size_t)n * 105 + 3 + e] * a.rmask[e];
-      }
-  } else if (a.losses) {
-    role -= kAsmElem;                    // [0, kAsmLoss)
-    float lsil = 0.f;
-    if (a.tile_loss) {
-      for (int k = role * 256 + t; k < M * a.T; k += kAsmLoss * 256) {
-        const int n = k / a.T;
-        const int Bn = frame_window_size(n, M, a.window);
-        lsil += a.tile_loss[k] * (a.w_sil / ((float)Bn * (float)a.S * (float)a.S));
-      }
-    }
-    // the queue kernels' partials are integers whose split over blocks varies from run to run: add them up as
-    // integers (exact, order-free) and convert the grand total once, in the last block
-    long long qs = 0;
-    if (a.qloss) for (int k = role * 256 + t; k < a.nqblk; k += kAsmLoss * 256) qs += a.qloss[k];
-    qs = wave_sum_i64(qs);
-    __shared__ long long qred[4];
-    if ((t & 63) == 0) qred[t >> 6] = qs;
-    lsil = block_sum(lsil, red);                        // (contains the barriers that also cover qred)
-    if (t == 0) { a.lpart[role] = lsil; a.qpart[role] = (qred[0] + qred[1]) + (qred[2] + qred[3]); }
-  }
-  if (!a.losses) return;
-  // ---- the last block to arrive finishes the loss terms: [joint, pose, splay, betas, sil, temp_joint, temp_global, temp_trans]
-  __threadfence();
-  __syncthreads();
-  if (t == 0) is_last = (atomicAdd(a.counter, 1) == (int)gridDim.x - 1);
-  __syncthreads();
-  if (!is_last) return;
-  __threadfence();
-  // silhouette: the kAsmLoss partials, one per lane, added in a fixed butterfly order
-  static_assert(kAsmLoss == 16, "butterfly below");
-  float lsil = 0.f;
-  if (t < 64) {
-    const volatile float* lp = a.lpart;
-    lsil = (t < kAsmLoss) ? lp[t] : 0.f;
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) lsil += __shfl_xor(lsil, o, 64);
-    const volatile long long* qp = a.qpart;
-    long long qtot = (t < kAsmLoss) ? qp[t] : 0ll;
-    qtot = wave_sum_i64(qtot);
-    lsil += (float)((double)qtot * (1.0 / (double)kLossFix));
-  }
-  // per-frame terms: 32 frame slices x 8 terms in parallel, then the slices in order
-  {
-    const int k = t & 7, sl = t >> 3;
-    float acc = 0.f;
-    if (a.loss_part) for (int n = sl; n < M; n += 32) acc += a.loss_part[n * 8 + k];
-    part[sl][k] = acc;
-  }
-  __syncthreads();
-  if (t < 8) {
-    float acc = 0.f;
-    if (t == 3) acc = a.loss_betas ? *a.loss_betas : 0.f;
-    else if (t == 4) acc = lsil;
-    else for (int i = 0; i < 32; ++i) acc += part[i][t];
-    a.losses[t] = acc;
-  }
-  if (t == 0) *a.counter = 0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// K12: Adam (torch.optim.Adam semantics: eps outside the bias-corrected sqrt)
-// ------------------------------------------------------------------------------------------------
-__global__ void adam_kernel(int count, float* __restrict__ p, const float* __restrict__ g,
-                            float* __restrict__ mm, float* __restrict__ vv,
-                            float step_size, float b1, float b2, float eps, float bc2_sqrt) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  const float gi = g[i];
-  const float mi = b1 * mm[i] + (1.0f - b1) * gi;
-  const float vi = b2 * vv[i] + (1.0f - b2) * gi * gi;
-  mm[i] = mi;
-  vv[i] = vi;
-  const float denom = sqrtf(vi) / bc2_sqrt + eps;
-  p[i] = p[i] - step_size * (mi / denom);
-}
-
-// ------------------------------------------------------------------------------------------------
-// temporal term on its own (SMALFitter.get_temporal called outside forward): M frames, one block
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(128)
-temporal_kernel(int M, float w_temp, const float* __restrict__ theta, const float* __restrict__ trans,
-                float* __restrict__ losses /*[3] joint, global, trans*/, float* __restrict__ dtheta /*[M][105]*/,
-                float* __restrict__ dtrans /*[M][3]*/) {
-  __shared__ float red[16];
-  const int t = threadIdx.x;
-  float lj = 0.f, lg = 0.f, lt = 0.f;
-  for (int idx = t; idx < M * 108; idx += 128) {
-    const int n = idx / 108, e = idx % 108;
-    const bool is_tr = e >= 105;
-    const int k = is_tr ? e - 105 : e;
-    const float D = is_tr ? 3.0f : (k < 3 ? 3.0f : 102.0f);
-    const float cur = is_tr ? trans[n * 3 + k] : theta[n * 105 + k];
-    float g = 0.f;
-    if (n + 1 < M) {
-      const float d = cur - (is_tr ? trans[(n + 1) * 3 + k] : theta[(n + 1) * 105 + k]);
-      const float term = d * d * (w_temp / D);
-      if (is_tr) lt += term; else if (k < 3) lg += term; else lj += term;
-      g += d;
-    }
-    if (n > 0) g += cur - (is_tr ? trans[(n - 1) * 3 + k] : theta[(n - 1) * 105 + k]);
-    g *= 2.0f * w_temp / D;
-    if (is_tr) dtrans[n * 3 + k] = g; else dtheta[n * 105 + k] = g;
-  }
-  lj = block_sum(lj, red); lg = block_sum(lg, red); lt = block_sum(lt, red);
-  if (t == 0) { losses[0] = lj; losses[1] = lg; losses[2] = lt; }
-}
-
-// apply masks to a (M,105) theta adjoint -> grads of global_rotation (M,3) and joint_rotations (M,102)
-__global__ void split_theta_grad_kernel(int M, const float* __restrict__ dtheta, const float* __restrict__ gmask,
-                                        const float* __restrict__ rmask, float* __restrict__ g_grot,
-                                        float* __restrict__ g_jrot) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= M * 105) return;
-  const int n = i / 105, e = i % 105;
-  if (e < 3) { if (g_grot) g_grot[n * 3 + e] = dtheta[i] * (gmask ? gmask[e] : 1.f); }
-  else if (g_jrot) g_jrot[n * 102 + e - 3] = dtheta[i] * (rmask ? rmask[e - 3] : 1.f);
-}
-
-// keypoint projection for arbitrary points (Renderer.forward points branch) + adjoint
-__global__ void project_points_kernel(int count, int S, const float* __restrict__ pts, float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  float xn, yn, zv;
-  world_to_ndc(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], xn, yn, zv);
-  const float half = 0.5f * (float)(S - 1);
-  out[i * 2] = half * (1.0f - yn);
-  out[i * 2 + 1] = half * (1.0f - xn);
-}
-__global__ void project_points_bwd_kernel(int count, int S, const float* __restrict__ pts,
-                                          const float* __restrict__ dout, float* __restrict__ dpts) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  float xn, yn, zv;
-  world_to_ndc(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], xn, yn, zv);
-  const float half = 0.5f * (float)(S - 1);
-  world_to_ndc_bwd(xn, yn, zv, -half * dout[i * 2 + 1], -half * dout[i * 2], dpts[i * 3], dpts[i * 3 + 1], dpts[i * 3 + 2]);
-}
-
-// Rodrigues on its own (batch_rodrigues drop-in) + adjoint
-__global__ void rodrigues_kernel(int count, const float* __restrict__ th, float* __restrict__ R) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  float r[9];
-  const float t[3] = {th[i * 3], th[i * 3 + 1], th[i * 3 + 2]};
-  rodrigues_fwd(t, r);
-#pragma unroll
-  for (int e = 0; e < 9; ++e) R[i * 9 + e] = r[e];
-}
-__global__ void rodrigues_bwd_kernel(int count, const float* __restrict__ th, const float* __restrict__ dR,
-                                     float* __restrict__ dth) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  const float t[3] = {th[i * 3], th[i * 3 + 1], th[i * 3 + 2]};
-  float g[9], d[3];
-#pragma unroll
-  for (int e = 0; e < 9; ++e) g[e] = dR[i * 9 + e];
-  rodrigues_bwd(t, g, d);
-  dth[i * 3] = d[0]; dth[i * 3 + 1] = d[1]; dth[i * 3 + 2] = d[2];
-}
-
-// Prior.__call__ on its own (pose_prior_35.py:117-124): out[n][c] = (((x - mu) P)[c] * mask[c])^2
-__global__ void __launch_bounds__(128)
-pose_prior_kernel(const float* __restrict__ x, const float* __restrict__ prec, const float* __restrict__ mean,
-                  const float* __restrict__ mask, float* __restrict__ out /*[N][105]*/) {
-  __shared__ float xs[105];
-  const int n = blockIdx.x, t = threadIdx.x;
-  if (t < 105) xs[t] = x[n * 105 + t] - mean[t];
-  __syncthreads();
-  if (t < 105) {
-    float acc = 0.f;
-    for (int r = 0; r < 105; ++r) acc = fmaf(xs[r], prec[r * 105 + t], acc);
-    acc *= mask[t];
-    out[n * 105 + t] = acc * acc;
-  }
-}
-// adjoint: dx[n][r] = sum_c dout[n][c] * 2 res[c] mask[c] P[r][c]
-__global__ void __launch_bounds__(128)
-pose_prior_bwd_kernel(const float* __restrict__ x, const float* __restrict__ prec, const float* __restrict__ mean,
-                      const float* __restrict__ mask, const float* __restrict__ dout, float* __restrict__ dx) {
-  __shared__ float xs[105], g[105];
-  const int n = blockIdx.x, t = threadIdx.x;
-  if (t < 105) xs[t] = x[n * 105 + t] - mean[t];
-  __syncthreads();
-  if (t < 105) {
-    float acc = 0.f;
-    for (int r = 0; r < 105; ++r) acc = fmaf(xs[r], prec[r * 105 + t], acc);
-    g[t] = 2.0f * acc * mask[t] * mask[t] * dout[n * 105 + t];
-  }
-  __syncthreads();
-  if (t < 105) {
-    float acc = 0.f;
-    for (int c = 0; c < 105; ++c) acc = fmaf(g[c], prec[t * 105 + c], acc);
-    dx[n * 105 + t] = acc;
-  }
-}
-
-__global__ void zero_int_kernel(int count, int* p) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < count) p[i] = 0;
-}
+#include "kernels_lbs_forward.inc"
+#include "kernels_raster.inc"
+#include "kernels_color.inc"
+#include "kernels_lbs_backward.inc"
 
 }  // namespace smalfit
 
