@@ -337,3 +337,48 @@ def case_sil_trajectory(M=4, S=64, window=2, iters=8, seed=21):
     for k in ("betas", "log_beta_scales", "global_rotation", "joint_rotations", "trans"):
         out["traj_%s_rel" % k] = rel(f.p[k].cpu().numpy().reshape(params[k].shape), params[k].numpy())
     return out
+
+
+def case_fit_family0_512(golden, M=2, S=512, window=2, stage=2, seed=43):
+    """BASELINE config 5's ingredients in one evaluation: a non-unity shape family (20-dim SMAL cluster prior from the
+    reference's golden data, per-frame (N,6) limb scales without a regulariser), 512 x 512 silhouettes, stage-2 weights."""
+    W = np.array(cfg.OPT_WEIGHTS).T
+    weights, w_temp = W[stage][:6].copy(), float(W[stage][6])
+    md0 = synthetic.synthetic_model(seed=0, shape_family_id=0)
+    om = so.OracleModel(md0)
+    dm = eng.DeviceModel(md0)
+    e = eng.Engine(dm, M, S)
+    e.set_pose_prior(golden["pose_prec"], golden["pose_mean"], golden["pose_mask"])
+    e.set_shape_prior(golden["fam0_prec"], golden["fam0_mean"])
+    gt = random_pose(M, seed, z=1.6)
+    cur = random_pose(M, seed, z=1.6)
+    rs = np.random.RandomState(seed + 7)
+    cur["global_rotation"] += (0.04 * rs.randn(M, 3)).astype(np.float32)
+    cur["joint_rotations"] += (0.06 * rs.randn(M, 34, 3)).astype(np.float32)
+    cur["trans"] += (0.02 * rs.randn(M, 3)).astype(np.float32)
+    cur["log_beta_scales"] = (0.1 * rs.randn(M, 6)).astype(np.float32)                 # per-frame limb scales
+    with torch.no_grad():
+        theta = np.concatenate([gt["global_rotation"][:, None], gt["joint_rotations"]], 1)
+        vo, jo, _, _ = so.smal_forward(om, torch.from_numpy(np.tile(gt["betas"], (M, 1))).double(),
+                                       torch.from_numpy(theta).double(),
+                                       torch.from_numpy(np.tile(gt["log_beta_scales"], (M, 1))).double())
+        t = torch.from_numpy(gt["trans"]).double()[:, None]
+        tj = so.project_points((jo + t)[:, so.CANONICAL], S).numpy() + rs.randn(M, 25, 2)
+        tsil = (so.soft_silhouette(vo + t, om.faces, S) > 0.5).double().numpy()
+    vis = (rs.rand(M, 25) < 0.85).astype(np.float32)
+    prob = so.FitProblem(om, S, tj, vis, tsil, golden["pose_prec"], golden["pose_mean"], golden["pose_mask"],
+                         golden["fam0_prec"], golden["fam0_mean"], window, use_unity_prior=False)
+    names = ("betas", "log_beta_scales", "global_rotation", "trans", "joint_rotations")
+    params64 = {k: torch.from_numpy(v).double() for k, v in cur.items()}
+    total, sums, grads_o = so.loss_and_grads(prob, params64, weights, w_temp, names)
+    d = {k: dev(v) for k, v in cur.items()}
+    losses, grads = e.fit_eval(betas=d["betas"], log_beta_scales=d["log_beta_scales"], global_rotation=d["global_rotation"],
+                               joint_rotations=d["joint_rotations"], trans=d["trans"], target_joints=dev(tj.astype(np.float32)),
+                               target_visibility=dev(vis), target_sil=dev(tsil.astype(np.float32)), weights=weights,
+                               w_temp=w_temp, window=window, want=names)
+    l = losses.cpu().numpy().astype(np.float64)
+    out = {"status": e.status(), "total_rel": abs(l.sum() - float(total)) / abs(float(total)),
+           "sil_oracle": sums.get("sil_reproj", 0.0), "sil_hip": float(l[4])}
+    for k in names:
+        out["grad_%s_rel" % k] = rel(grads[k].cpu().numpy(), grads_o[k].numpy())
+    return out

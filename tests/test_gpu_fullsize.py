@@ -166,3 +166,14 @@ def test_fit_single_image_configuration():
     for k, v in m.items():
         if k.startswith("fit_grad_") and k.endswith("_rel"):
             assert v < 2e-3, (k, v, m)
+
+
+def test_fit_non_unity_family_with_per_frame_limb_scales_at_512(golden):
+    """BASELINE config 5's ingredients: shape family 0 (20-dim SMAL prior), per-frame (N,6) limb scales, 512^2 silhouettes"""
+    m = pc.case_fit_family0_512(golden)
+    assert m["status"] == 0
+    assert m["sil_oracle"] > 0.0
+    assert m["total_rel"] < 1e-4, m
+    for k, v in m.items():
+        if k.startswith("grad_"):
+            assert v < 2e-3, (k, v, m)

@@ -99,10 +99,11 @@ def test_raster_cache_never_changes_results():
         assert m["status"] == 0
 
 
-def test_fit_loop_with_silhouette_follows_the_oracle():
+@pytest.mark.parametrize("M,S,window,iters", [(4, 64, 2, 8), (8, 128, 4, 5)])
+def test_fit_loop_with_silhouette_follows_the_oracle(M, S, window, iters):
     """8 iterations of the whole loop with the silhouette term on (cached depth bounds included): losses and parameters
     against the oracle's loss + autograd + Adam.  north_star's bar for parameters is 1e-4 relative L2."""
-    m = pc.case_sil_trajectory()
+    m = pc.case_sil_trajectory(M, S, window, iters)
     assert m["traj_status"] == 0
     assert m["traj_loss_rel_max"] < 1e-4, m
     for k, v in m.items():
