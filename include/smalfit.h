@@ -69,8 +69,8 @@ int smalfit_engine_reset_raster_cache(smalfit_engine* engine, void* stream);
  * profile_end synchronises `stream`, and returns the summed milliseconds and the number of timed evaluations per
  * section. */
 #define SMALFIT_NUM_SECTIONS 6
-#define SMALFIT_SEC_LBS_FWD 0        /* shape + pose + skin + joints kernels                     */
-#define SMALFIT_SEC_RASTER_SWEEP 1   /* accumulator memset + face_bbox_kernel + raster_sweep_kernel */
+#define SMALFIT_SEC_LBS_FWD 0        /* lbs_head (pose, shape blend, shape prior) + skin + joints kernels */
+#define SMALFIT_SEC_RASTER_SWEEP 1   /* face_bbox_kernel + raster_sweep_kernel                     */
 #define SMALFIT_SEC_RASTER_SELECT 2  /* raster_select_kernel alone (K-nearest selection)          */
 #define SMALFIT_SEC_RASTER_BWD 3     /* raster_bwd_kernel alone                                   */
 #define SMALFIT_SEC_LBS_BWD 4        /* vertex, mid-stage (dA, pose-blend, shape-blend) and chain adjoints */
