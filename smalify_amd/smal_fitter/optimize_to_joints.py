@@ -1,9 +1,8 @@
 """Counterpart of reference smal_fitter/optimize_to_joints.py: the stage / epoch driver.
 
-`main()` runs the fused on-device loop (smalify_amd.fitter.FusedFitter) with the reference's schedule and
-writes the same per-frame checkpoint files (st{stage}_ep{epoch}.pkl / .ply, final st10_ep0).  Dataset
-loading (BADJA / StanfordExtra json + images) is outside the accelerated path: pass the reference loader's
-output tuple `(rgb, sil, joints, visibility), filenames` to `fit_sequence`."""
+`main()` loads the configured sequence (data_loader.py), runs the fused on-device loop (smalify_amd.fitter.FusedFitter)
+with the reference's schedule and writes the same per-frame checkpoint files (st{stage}_ep{epoch}.pkl / .ply, final
+st10_ep0).  `fit_sequence` takes the loader's output tuple `(rgb, sil, joints, visibility), filenames` directly."""
 from __future__ import annotations
 
 import os
@@ -101,6 +100,25 @@ def fit_sequence(data, filenames, model_data, pose_prior, shape_prior, use_unity
 
 
 def main():
-    raise SystemExit("smalify_amd.smal_fitter.optimize_to_joints.main: load a sequence with the reference's "
-                     "data_loader and call fit_sequence(data, filenames, model_io.load_smal_model(...), "
-                     "model_io.load_pose_prior(...), model_io.unity_shape_prior(...)).")
+    """reference optimize_to_joints.py:55-144: dataset from config.SEQUENCE_OR_IMAGE_NAME, model / priors from the config
+    paths (data root: $SMALIFY_DATA), the full schedule, checkpoints under config.OUTPUT_DIR."""
+    from .data_loader import load_badja_sequence, load_stanford_sequence
+    os.makedirs(config.OUTPUT_DIR, exist_ok=True)
+    dataset, name = config.SEQUENCE_OR_IMAGE_NAME.split(":")
+    if dataset == "badja":
+        data, filenames = load_badja_sequence(config.BADJA_PATH, name, config.CROP_SIZE, image_range=config.IMAGE_RANGE)
+    else:
+        data, filenames = load_stanford_sequence(config.STANFORD_EXTRA_PATH, name, config.CROP_SIZE)
+    print("Dataset size: {0}".format(len(filenames)))
+    assert config.SHAPE_FAMILY >= 0, "Shape family should be greater than 0"
+    use_unity_prior = config.SHAPE_FAMILY == 1 and not config.FORCE_SMAL_PRIOR
+    model_data = model_io.load_smal_model(config.SMAL_FILE, config.SMAL_DATA_FILE, config.SMAL_SYM_FILE, config.SHAPE_FAMILY)
+    pose_prior = model_io.load_pose_prior(config.WALKING_PRIOR_FILE)
+    shape_prior = (model_io.unity_shape_prior(config.UNITY_SHAPE_PRIOR) if use_unity_prior
+                   else model_io.family_shape_prior(model_io.load_pickle(config.SMAL_DATA_FILE), config.SHAPE_FAMILY))
+    return fit_sequence(data, filenames, model_data, pose_prior, shape_prior, use_unity_prior=use_unity_prior,
+                        output_dir=config.OUTPUT_DIR)
+
+
+if __name__ == "__main__":
+    main()

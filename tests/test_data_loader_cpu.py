@@ -1,0 +1,112 @@
+"""CPU tests of the cv2 / imageio / pycocotools-free data loaders.  The original packages are not
+installed here, so these are known answers of their documented behaviour plus self-consistency on synthetic datasets
+written in the two on-disk formats."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from smalify_amd import config  # noqa: E402
+from smalify_amd.smal_fitter import data_loader as dl  # noqa: E402
+from smalify_amd.smal_fitter.optimize_to_joints import write_png  # noqa: E402
+from smalify_amd.smal_fitter.utils import crop_to_silhouette, resize_linear, resize_nearest  # noqa: E402
+
+
+def test_resize_follows_cv2_conventions():
+    # cv2.resize([[0, 1]], (4, 1), INTER_LINEAR) -> half-pixel centres, clamped border
+    assert np.allclose(resize_linear(np.array([[0.0, 1.0]]), 1, 4), [[0.0, 0.25, 0.75, 1.0]])
+    # cv2.resize(arange(4), (2, 1), INTER_NEAREST) -> floor(x * 2): elements 0 and 2
+    assert np.array_equal(resize_nearest(np.arange(4.0)[None], 1, 2), [[0.0, 2.0]])
+    # downscaling by 2 with INTER_LINEAR averages pixel pairs, no antialiasing beyond that
+    assert np.allclose(resize_linear(np.arange(8.0)[None], 1, 4), [[0.5, 2.5, 4.5, 6.5]])
+    img = np.random.RandomState(0).rand(5, 7, 3)
+    assert np.array_equal(resize_nearest(img, 5, 7), img) and np.allclose(resize_linear(img, 5, 7), img)
+
+
+def test_rle_known_answers_and_round_trip():
+    # pycocotools: a full 2x2 mask is the runs [0, 4] -> "04"; an empty one is [4] -> "4"
+    assert dl.encode_rle(np.ones((2, 2), np.uint8)) == "04" and dl.encode_rle(np.zeros((2, 2), np.uint8)) == "4"
+    assert np.array_equal(dl.decode_rle("04", 2, 2), np.ones((2, 2)))
+    # column-major runs: a 2x3 mask with only element (row 1, col 0) set is runs [1, 1, 4]
+    m = np.zeros((2, 3), np.uint8); m[1, 0] = 1
+    assert dl.encode_rle(m) == "114" and np.array_equal(dl.decode_rle("114", 2, 3), m)
+    rs = np.random.RandomState(1)
+    for _ in range(40):
+        h, w = rs.randint(1, 60), rs.randint(1, 60)
+        mask = (rs.rand(h, w) < rs.rand()).astype(np.uint8)
+        assert np.array_equal(dl.decode_rle(dl.encode_rle(mask), h, w), mask)
+    big = np.zeros((300, 200), np.uint8); big[40:260, 30:170] = 1          # runs > 31 need several 5-bit groups, deltas go negative
+    assert np.array_equal(dl.decode_rle(dl.encode_rle(big), 300, 200), big)
+
+
+def test_crop_to_silhouette_geometry():
+    sil = np.zeros((60, 80)); sil[20:40, 30:70] = 1.0                  # 20 x 40 blob centred at (29.5, 49.5)
+    rgb = np.zeros((60, 80, 3)); rgb[20:40, 30:70] = 0.5
+    joints = np.array([[20.0, 30.0], [39.0, 69.0]])                    # its corners, (row, col)
+    s, r, j = crop_to_silhouette(sil, rgb, joints, 64)
+    assert s.shape == (64, 64) and r.shape == (64, 64, 3)
+    half = int(1.05 * (39 / 2))                                         # larger extent is 39 pixels
+    scale = 64 / (2.0 * half)
+    cy, cx = 20 + int(19 / 2), 30 + int(39 / 2)
+    assert np.allclose(j, (joints - [cy - half, cx - half]) * scale)
+    assert set(np.unique(s)) <= {0.0, 1.0} and 0.4 < s.mean() * (2 * half) ** 2 / (20 * 40) < 1.6
+    assert np.allclose(r[s > 0].mean(), 0.5, atol=0.05) and r.max() <= 1.0
+
+
+def _write_badja(root):
+    os.makedirs(os.path.join(root, "joint_annotations"))
+    os.makedirs(os.path.join(root, "seq"))
+    entries = []
+    rs = np.random.RandomState(2)
+    for i in range(3):
+        img = (rs.rand(48, 64, 3) * 255).astype(np.uint8)
+        seg = np.zeros((24, 32, 3), np.uint8); seg[6 + i:18, 8:24] = 255       # half resolution, as in BADJA
+        write_png(os.path.join(root, "seq", "%04d.png" % i), img)
+        write_png(os.path.join(root, "seq", "%04d_seg.png" % i), seg)
+        entries.append({"image_path": "seq/%04d.png" % i, "segmentation_path": "seq/%04d_seg.png" % i,
+                        "joints": (rs.rand(40, 2) * [48, 64]).tolist(), "visibility": (rs.rand(40) < 0.7).astype(int).tolist()})
+    entries.append({"image_path": "seq/missing.png", "segmentation_path": "seq/missing_seg.png", "joints": [[0, 0]] * 40,
+                    "visibility": [0] * 40})
+    with open(os.path.join(root, "joint_annotations", "synth.json"), "w") as fh:
+        json.dump(entries, fh)
+    return entries
+
+
+def test_load_badja_sequence_on_a_synthetic_dataset(tmp_path, capsys):
+    root = str(tmp_path / "BADJA")
+    entries = _write_badja(root)
+    (rgb, sil, joints, vis), names = dl.load_badja_sequence(root, "synth", 32, image_range=range(0, 4))
+    assert names == ["0000.png", "0001.png", "0002.png"] and "missing" in capsys.readouterr().out
+    assert rgb.shape == (3, 3, 32, 32) and sil.shape == (3, 1, 32, 32) and joints.shape == (3, 25, 2) and vis.shape == (3, 25)
+    assert rgb.dtype == sil.dtype == joints.dtype == vis.dtype
+    assert float(rgb.min()) >= 0.0 and float(rgb.max()) <= 1.0 and 0.2 < float(sil.mean()) < 0.9
+    unlabelled = np.array(config.BADJA_ANNOTATED_CLASSES) == -1
+    assert float(vis[:, unlabelled].abs().max()) == 0.0
+    labelled = np.flatnonzero(~unlabelled)
+    want = np.array(entries[1]["visibility"])[np.array(config.BADJA_ANNOTATED_CLASSES)[labelled]]
+    assert np.array_equal(vis[1, labelled].numpy(), want.astype(np.float32))
+
+
+def test_load_stanford_sequence_on_a_synthetic_dataset(tmp_path):
+    root = str(tmp_path / "StanfordExtra")
+    os.makedirs(os.path.join(root, "sample_imgs", "n0-dog"))
+    rs = np.random.RandomState(3)
+    img = (rs.rand(50, 70, 3) * 255).astype(np.uint8)
+    write_png(os.path.join(root, "sample_imgs", "n0-dog", "a.png"), img)
+    mask = np.zeros((50, 70), np.uint8); mask[10:40, 20:60] = 1
+    joints = np.concatenate([rs.rand(24, 2) * [70, 50], (rs.rand(24, 1) < 0.8)], 1)     # (x, y, visible)
+    with open(os.path.join(root, "StanfordExtra_sample.json"), "w") as fh:
+        json.dump([{"img_path": "n0-dog/a.png", "img_height": 50, "img_width": 70, "seg": dl.encode_rle(mask),
+                    "joints": joints.tolist()}], fh)
+    (rgb, sil, j, vis), names = dl.load_stanford_sequence(root, "n0-dog/a.png", 40)
+    assert names == ["a.png"] and rgb.shape == (1, 3, 40, 40) and sil.shape == (1, 1, 40, 40)
+    assert j.shape == (1, 25, 2) and vis.shape == (1, 25) and float(vis[0, 24]) == 0.0        # the added tail-middle joint
+    assert set(np.unique(sil.numpy())) <= {0.0, 1.0}
+    half = int(1.05 * (39 / 2))
+    cy, cx = 10 + int(29 / 2), 20 + int(39 / 2)
+    want = (joints[:, [1, 0]] - [cy - half, cx - half]) * (40 / (2.0 * half))                  # (row, col) in the crop
+    assert np.allclose(j[0, :24].numpy(), want, atol=1e-4)
