@@ -176,6 +176,46 @@ int smalfit_temporal(smalfit_engine* engine, void* stream, int N, float w_temp, 
                      const float* rotation_mask, float* losses, float* g_global_rotation,
                      float* g_joint_rotations, float* g_trans);
 
+/* ---- fitter_3d: SMAL-to-mesh objective -----------------------------------------
+ * replaces: Stage.forward / Stage.step                       reference fitter_3d/trainer.py:205-241
+ * and the PyTorch3D v0.2.5 calls inside it (sample_points_from_meshes, chamfer_distance, mesh_edge_loss,
+ * mesh_normal_consistency, mesh_laplacian_smoothing("uniform")) together with their autograd.
+ *
+ * smalfit_mesh_objective: the deforming source meshes, all of one topology (faces: host, (F,3) int32; every face
+ * must have 3 distinct vertices).  Holds the edge / one-ring / face-pair tables and the work buffers for up to
+ * max_meshes meshes and max_points target points per mesh. */
+typedef struct smalfit_mesh_objective smalfit_mesh_objective;
+typedef struct smalfit_mesh_targets smalfit_mesh_targets;
+#define SMALFIT_NUM_MESH_LOSS_TERMS 5 /* chamfer, edge, normal, laplacian (unweighted), weighted total */
+
+int smalfit_mesh_objective_create(int num_verts, int num_faces, const int* faces /*host*/, int max_meshes,
+                                  int max_points, smalfit_mesh_objective** out);
+void smalfit_mesh_objective_destroy(smalfit_mesh_objective* objective);
+/* unique edges and pairs of faces sharing an edge (Meshes.edges_packed; the pair table of mesh_normal_consistency) */
+int smalfit_mesh_objective_counts(const smalfit_mesh_objective* objective, int* num_edges, int* num_face_pairs);
+/* verts = lbs_verts + trans + deform_verts (SMAL3DFitter.forward, trainer.py:94-108; deform_verts may be NULL), then
+ * losses[0..3] = chamfer(points, verts), edge, normal, laplacian; losses[4] = sum of weights[i] * term over the terms
+ * with weights[i] > 0 (weights: host, order w_chamfer, w_edge, w_normal, w_laplacian; trainer.py:31,203).
+ * lbs_verts (N,V,3)  trans (N,3)  deform_verts (N,V,3)  points (N,S,3) (ignored when w_chamfer <= 0)
+ * -> verts_out (N,V,3) or NULL, losses (5, device), dverts (N,V,3) = d total / d verts (also the gradient of
+ * deform_verts), dtrans (N,3).  Chain dverts through smalfit_lbs_backward for the SMAL parameters. */
+int smalfit_mesh_objective_eval(smalfit_mesh_objective* objective, void* stream, int num_meshes,
+                                const float* lbs_verts, const float* trans, const float* deform_verts,
+                                const float* points, int num_points, const float* weights /*host*/,
+                                float* verts_out, float* losses, float* dverts, float* dtrans);
+
+/* smalfit_mesh_targets: the target meshes, packed (all arguments host): vert_counts / face_counts (num_meshes),
+ * verts (sum V,3), faces (sum F,3) with indices local to each mesh.
+ * replaces: the Meshes object of fitter_3d/utils.py:253 as far as sample_points_from_meshes needs it */
+int smalfit_mesh_targets_create(int num_meshes, const int* vert_counts, const int* face_counts, const float* verts,
+                                const int* faces, smalfit_mesh_targets** out);
+void smalfit_mesh_targets_destroy(smalfit_mesh_targets* targets);
+/* replaces: sample_points_from_meshes(target_meshes, num_points)   trainer.py:209
+ * face ~ area, barycentric (1 - sqrt u, sqrt u (1 - v), sqrt u v); Philox-4x32-10 keyed by `seed`, counter
+ * (sample, mesh, iteration): the same (seed, iteration) always gives the same points.  points (N,S,3) device. */
+int smalfit_mesh_targets_sample(smalfit_mesh_targets* targets, void* stream, int num_points,
+                                unsigned long long seed, unsigned int iteration, float* points);
+
 /* ---- torch.optim.Adam.step -----------------------------------------------------------------------
  * replaces: torch.optim.Adam(lr, betas=(0.5, 0.999)).step()  reference smal_fitter/optimize_to_joints.py:96,137
  * t = 1-based step count; eps outside the bias-corrected sqrt, as torch does */

@@ -71,6 +71,13 @@ SIGNATURES = {
     "smalfit_pose_prior_backward": (_I, [_VP, _VP, _I, _VP, _VP, _VP]),
     "smalfit_temporal": (_I, [_VP, _VP, _I, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "smalfit_adam_step": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _F, _F, _F, _F, _I]),
+    "smalfit_mesh_objective_create": (_I, [_I, _I, _VP, _I, _I, C.POINTER(_VP)]),
+    "smalfit_mesh_objective_destroy": (None, [_VP]),
+    "smalfit_mesh_objective_counts": (_I, [_VP, c_int_p, c_int_p]),
+    "smalfit_mesh_objective_eval": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
+    "smalfit_mesh_targets_create": (_I, [_I, _VP, _VP, _VP, _VP, C.POINTER(_VP)]),
+    "smalfit_mesh_targets_destroy": (None, [_VP]),
+    "smalfit_mesh_targets_sample": (_I, [_VP, _VP, _I, C.c_ulonglong, C.c_uint, _VP]),
 }
 
 

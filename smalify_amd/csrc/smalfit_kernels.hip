@@ -9,8 +9,8 @@
 //   with 35 entries per row, the code path is the same and the sums run in the same joint order.
 //
 // One translation unit: this file holds the shared device helpers and includes the kernels by subsystem
-// (kernels_lbs_forward.inc, kernels_raster.inc, kernels_color.inc, kernels_lbs_backward.inc), then the host side
-// (smalfit_launch.inc).
+// (kernels_lbs_forward.inc, kernels_raster.inc, kernels_color.inc, kernels_lbs_backward.inc, kernels_mesh3d.inc), then
+// the host side (smalfit_launch.inc, smalfit_mesh3d.inc).
 //
 // Kernel -> reference map (file:line into /root/reference):
 //   lbs_head_kernel     pose blocks: batch_lbs.py:33-52 (Rodrigues), :105-129 (limb scales), :131-168 (chain, A);
@@ -23,10 +23,13 @@
 //                       p3d_renderer.py:26-39,65-66 (pytorch3d rasterize_meshes + sigmoid_alpha_blend)
 //   vertex_bwd, lbs_bwd_mid, chain_bwd, assemble    autograd of the above (optimize_to_joints.py:136)
 //   adam_kernel         optimize_to_joints.py:96,137 (torch.optim.Adam, betas=(0.5,0.999))
+//   mesh3d_*            fitter_3d/trainer.py:205-227 (pytorch3d sample_points_from_meshes, chamfer_distance, mesh_edge_loss,
+//                       mesh_normal_consistency, mesh_laplacian_smoothing) and their adjoints
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "smalfit_internal.h"
+#include "mesh3d_math.h"
 
 namespace smalfit {
 
@@ -92,7 +95,9 @@ __device__ __forceinline__ int frame_window_size(int n, int M, int window) {
 #include "kernels_raster.inc"
 #include "kernels_color.inc"
 #include "kernels_lbs_backward.inc"
+#include "kernels_mesh3d.inc"
 
 }  // namespace smalfit
 
 #include "smalfit_launch.inc"
+#include "smalfit_mesh3d.inc"

@@ -285,3 +285,107 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, t, beta1=0.5, beta2=0.999, e
     lib = _lib.load()
     check(lib.smalfit_adam_step(_stream(), int(param.numel()), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
                                 float(lr), float(beta1), float(beta2), float(eps), int(t)), "smalfit_adam_step")
+
+
+# ---- fitter_3d: SMAL-to-mesh objective ------------------------------------------------------
+MESH_LOSS_NAMES = ("chamfer", "edge", "normal", "laplacian", "total")
+
+
+class MeshObjective:
+    """Chamfer + edge + normal-consistency + uniform-Laplacian objective of N deforming meshes of one topology and its
+    gradient (smalfit_mesh_objective; reference fitter_3d/trainer.py:205-227 + the PyTorch3D v0.2.5 losses)."""
+
+    def __init__(self, num_verts, faces, max_meshes, max_points):
+        if not torch.cuda.is_available():
+            raise SmalfitError("no HIP device available: smalify_amd has no CPU fallback")
+        self.lib = _lib.load()
+        f = _host(faces, np.int32).reshape(-1, 3)
+        self.num_verts, self.num_faces = int(num_verts), int(f.shape[0])
+        self.max_meshes, self.max_points = int(max_meshes), int(max_points)
+        torch.cuda.init()
+        torch.cuda.current_device()
+        h = C.c_void_p()
+        check(self.lib.smalfit_mesh_objective_create(self.num_verts, self.num_faces, f.ctypes.data, self.max_meshes,
+                                                     self.max_points, C.byref(h)), "smalfit_mesh_objective_create")
+        self.handle = h
+        ne, npairs = C.c_int(), C.c_int()
+        check(self.lib.smalfit_mesh_objective_counts(h, C.byref(ne), C.byref(npairs)), "smalfit_mesh_objective_counts")
+        self.num_edges, self.num_face_pairs = ne.value, npairs.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.smalfit_mesh_objective_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def eval(self, lbs_verts, trans, deform_verts, points, weights, out=None):
+        """-> dict(losses (5,), verts (N,V,3), dverts (N,V,3), dtrans (N,3)); `weights` = (w_chamfer, w_edge, w_normal,
+        w_laplacian) host floats; `out` may carry preallocated tensors under the same keys"""
+        N, V = int(lbs_verts.shape[0]), self.num_verts
+        if tuple(lbs_verts.shape) != (N, V, 3) or tuple(trans.shape) != (N, 3):
+            raise SmalfitError("lbs_verts must be (N,%d,3) and trans (N,3)" % V)
+        if deform_verts is not None and tuple(deform_verts.shape) != (N, V, 3):
+            raise SmalfitError("deform_verts must be (N,%d,3)" % V)
+        S = 0
+        if points is not None:
+            if points.dim() != 3 or int(points.shape[0]) != N or int(points.shape[2]) != 3:
+                raise SmalfitError("points must be (N,S,3)")
+            S = int(points.shape[1])
+        dev = lbs_verts.device
+        o = out if out is not None else {}
+        for k, shape in (("losses", (5,)), ("verts", (N, V, 3)), ("dverts", (N, V, 3)), ("dtrans", (N, 3))):
+            if k not in o or tuple(o[k].shape) != shape:
+                o[k] = torch.empty(shape, device=dev)
+        w = _host(weights, np.float32).reshape(4)
+        check(self.lib.smalfit_mesh_objective_eval(self.handle, _stream(), N, _ptr(lbs_verts), _ptr(trans),
+                                                   _ptr(deform_verts), _ptr(points), S, w.ctypes.data, _ptr(o["verts"]),
+                                                   _ptr(o["losses"]), _ptr(o["dverts"]), _ptr(o["dtrans"])),
+              "smalfit_mesh_objective_eval")
+        return o
+
+
+class MeshTargets:
+    """Target meshes resident in HBM + the area-weighted point sampler (smalfit_mesh_targets; reference
+    fitter_3d/utils.py:253 Meshes(...) and trainer.py:209 sample_points_from_meshes)."""
+
+    def __init__(self, verts_list, faces_list):
+        if not torch.cuda.is_available():
+            raise SmalfitError("no HIP device available: smalify_amd has no CPU fallback")
+        if len(verts_list) == 0 or len(verts_list) != len(faces_list):
+            raise SmalfitError("need one (verts, faces) pair per target mesh")
+        self.lib = _lib.load()
+        self.verts_list = [_host(v, np.float32).reshape(-1, 3) for v in verts_list]
+        self.faces_list = [_host(f, np.int32).reshape(-1, 3) for f in faces_list]
+        vc = np.array([len(v) for v in self.verts_list], np.int32)
+        fc = np.array([len(f) for f in self.faces_list], np.int32)
+        vv = np.ascontiguousarray(np.concatenate(self.verts_list, axis=0))
+        ff = np.ascontiguousarray(np.concatenate(self.faces_list, axis=0))
+        torch.cuda.init()
+        torch.cuda.current_device()
+        h = C.c_void_p()
+        check(self.lib.smalfit_mesh_targets_create(len(vc), vc.ctypes.data, fc.ctypes.data, vv.ctypes.data,
+                                                   ff.ctypes.data, C.byref(h)), "smalfit_mesh_targets_create")
+        self.handle = h
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    def __len__(self):
+        return len(self.verts_list)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.smalfit_mesh_targets_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def sample(self, num_points, seed, iteration, out=None):
+        """(N, num_points, 3) points; the same (seed, iteration) always gives the same points"""
+        N = len(self)
+        if out is None or tuple(out.shape) != (N, int(num_points), 3):
+            out = torch.empty(N, int(num_points), 3, device=self.device)
+        check(self.lib.smalfit_mesh_targets_sample(self.handle, _stream(), int(num_points), int(seed) & (2 ** 64 - 1),
+                                                   int(iteration) & 0xFFFFFFFF, _ptr(out)), "smalfit_mesh_targets_sample")
+        return out

@@ -1,0 +1,293 @@
+"""CPU checks for the 3D mesh-fitting objective.
+
+1. the oracle (oracle/mesh3d_oracle.py, torch float64) against closed forms on small meshes -- PyTorch3D is absent, these
+   are the only anchors the restated v0.2.5 losses have ("parity unpinned", see the oracle's header);
+2. the per-element device maths and the C++ topology builder (smalify_amd/csrc/mesh3d_math.h, mesh3d_topology.h, compiled
+   for the host by g++ in a test-only shim that drives them exactly like the kernels do) against the oracle's autograd
+   on the full-size synthetic SMAL mesh;
+3. the sampler: Philox known answers, area-proportional face frequencies, determinism."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mesh3d_oracle as mo
+from smalify_amd import synthetic
+from tests import mesh3d_cases as mc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "host_mesh3d_shim.cpp")
+SO = os.path.join(HERE, "_build", "libhost_mesh3d_shim.so")
+CSRC = os.path.join(HERE, "..", "smalify_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def shim():
+    os.makedirs(os.path.dirname(SO), exist_ok=True)
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("mesh3d_math.h", "mesh3d_topology.h", "smalfit_math.h")]
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", SRC, "-o", SO], check=True)
+    return C.CDLL(SO)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+CUBE_V = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], np.float64)
+CUBE_F = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [1, 2, 6], [1, 6, 5],
+                   [2, 3, 7], [2, 7, 6], [3, 0, 4], [3, 4, 7]], np.int64)          # outward-facing unit cube
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 1. oracle vs closed forms
+# ---------------------------------------------------------------------------------------------------------------
+def test_oracle_cube_closed_forms():
+    edges = mo.unique_edges(CUBE_F)
+    pairs = mo.face_pairs(CUBE_F)
+    assert edges.shape == (18, 2) and pairs.shape == (18, 4)          # 12 cube edges + 6 face diagonals, closed manifold
+    v = torch.from_numpy(CUBE_V)[None]
+    # 12 unit edges + 6 diagonals of squared length 2
+    assert abs(float(mo.edge_loss(v, edges)) - (12 * 1.0 + 6 * 2.0) / 18) < 1e-12
+    # the 6 diagonals join coplanar triangles (1 - cos = 0), the 12 cube edges join perpendicular faces (1 - cos = 1)
+    assert abs(float(mo.normal_consistency(v, pairs)) - 12.0 / 18.0) < 1e-12
+    # uniform Laplacian by hand
+    nb = [set() for _ in range(8)]
+    for a, b in edges:
+        nb[a].add(b)
+        nb[b].add(a)
+    want = np.mean([np.linalg.norm(CUBE_V[sorted(s)].mean(0) - CUBE_V[i]) for i, s in enumerate(nb)])
+    assert abs(float(mo.laplacian_uniform(v, edges)) - want) < 1e-12
+    # scaling the mesh by s scales: edge by s^2, laplacian by s, normal consistency not at all
+    s = 0.37
+    assert abs(float(mo.edge_loss(v * s, edges)) - s * s * 24 / 18) < 1e-12
+    assert abs(float(mo.laplacian_uniform(v * s, edges)) - s * want) < 1e-12
+    assert abs(float(mo.normal_consistency(v * s, pairs)) - 12.0 / 18.0) < 1e-12
+
+
+def test_oracle_chamfer_closed_form():
+    verts = torch.tensor([[[0.0, 0, 0], [1, 0, 0], [0, 2, 0]]], dtype=torch.float64)
+    pts = torch.tensor([[[0.1, 0, 0], [1, 0.5, 0]]], dtype=torch.float64)
+    # points -> verts: 0.01, 0.25 ; verts -> points: 0.01, 0.25, min(0.01 + 4, 1 + 2.25) = 3.25
+    want = (0.01 + 0.25) / 2 + (0.01 + 0.25 + 3.25) / 3
+    assert abs(float(mo.chamfer(pts, verts)) - want) < 1e-12
+    # batch mean: two copies give the same value
+    assert abs(float(mo.chamfer(pts.repeat(2, 1, 1), verts.repeat(2, 1, 1))) - want) < 1e-12
+
+
+def test_oracle_normal_consistency_clamp_and_fold():
+    # two triangles folded flat onto each other: normals opposite, 1 - cos = 2
+    v = torch.tensor([[[0.0, 0, 0], [1, 0, 0], [0.3, 1, 0], [0.6, 0.8, 0]]], dtype=torch.float64)
+    f = np.array([[0, 1, 2], [1, 0, 3]])
+    assert abs(float(mo.normal_consistency(v, mo.face_pairs(f))) - 2.0) < 1e-12
+    # tiny faces: |n0|^2 |n1|^2 < 1e-16 -> the clamp of torch's cosine_similarity takes over, cos = <n0,n1> / 1e-8
+    tiny = v * 1e-3
+    tiny[0, 3, 2] = 1e-4
+    p = mo.face_pairs(f)
+    e, ea, eb = (tiny[0, 1] - tiny[0, 0]), (tiny[0, 2] - tiny[0, 0]), (tiny[0, 3] - tiny[0, 0])
+    n0, n1 = torch.linalg.cross(e, ea), -torch.linalg.cross(e, eb)
+    assert float((n0 @ n0) * (n1 @ n1)) < 1e-16
+    assert abs(float(mo.normal_consistency(tiny, p)) - (1.0 - float(n0 @ n1) / 1e-8)) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 2. device maths + topology builder (host shim) vs oracle
+# ---------------------------------------------------------------------------------------------------------------
+def _shim_topology(shim, V, faces):
+    faces = np.ascontiguousarray(faces, np.int32)
+    counts = np.zeros(4, np.int32)
+    assert shim.hm3_topology(V, len(faces), _p(faces), _p(counts), None, None, None, None, None) == 0
+    E, P, ln, li = (int(c) for c in counts)
+    nbr_off, nbr = np.zeros(V + 1, np.int32), np.zeros(ln, np.int32)
+    pairs, inc_off, inc = np.zeros((P, 4), np.int32), np.zeros(V + 1, np.int32), np.zeros(li, np.int32)
+    assert shim.hm3_topology(V, len(faces), _p(faces), _p(counts), _p(nbr_off), _p(nbr), _p(pairs), _p(inc_off), _p(inc)) == 0
+    return E, P, nbr_off, nbr, pairs, inc_off, inc
+
+
+def test_topology_builder_matches_oracle(shim):
+    md = synthetic.synthetic_model(seed=0, shape_family_id=1)
+    faces = np.asarray(md.faces, np.int64)
+    V = md.num_verts
+    E, P, nbr_off, nbr, pairs, inc_off, inc = _shim_topology(shim, V, faces)
+    edges = mo.unique_edges(faces)
+    want_pairs = mo.face_pairs(faces)
+    assert E == len(edges) and P == len(want_pairs)
+    # the one-ring CSR holds exactly the unique edges, neighbours ascending
+    got = set()
+    for v in range(V):
+        ring = nbr[nbr_off[v]:nbr_off[v + 1]]
+        assert np.all(np.diff(ring) > 0)
+        got.update((min(v, u), max(v, u)) for u in ring)
+    assert got == set(map(tuple, edges))
+    # same pair rows up to the order of the two opposite vertices
+    canon = lambda a: sorted((r[0], r[1], min(r[2], r[3]), max(r[2], r[3])) for r in a.tolist())  # noqa: E731
+    assert canon(pairs) == canon(want_pairs)
+    # incidence: every slot exactly once, under its own vertex, ascending
+    assert sorted(inc.tolist()) == list(range(4 * P))
+    flat = pairs.reshape(-1)
+    for v in range(0, V, 97):
+        slots = inc[inc_off[v]:inc_off[v + 1]]
+        assert np.all(flat[slots] == v) and np.all(np.diff(slots) > 0)
+    # rejected inputs
+    bad = np.array([[0, 1, 1]], np.int32)
+    assert shim.hm3_topology(3, 1, _p(bad), _p(np.zeros(4, np.int32)), None, None, None, None, None) == 1
+    bad = np.array([[0, 1, 5]], np.int32)
+    assert shim.hm3_topology(3, 1, _p(bad), _p(np.zeros(4, np.int32)), None, None, None, None, None) == 1
+
+
+_problem = mc.objective_problem
+
+
+@pytest.mark.parametrize("N,S,weights", [(2, 3000, (1.0, 1.0, 0.01, 0.1)), (1, 1500, (1.0, 0.8, 0.02, 0.01)),
+                                         (2, 700, (0.0, 1.0, 0.5, 0.3))])
+def test_objective_maths_matches_oracle(shim, N, S, weights):
+    md, lbs, trans, dfm, pts = _problem(N, S, seed=5 + N + S)
+    V, faces = md.num_verts, np.ascontiguousarray(md.faces, np.int32)
+    verts = np.zeros((N, V, 3), np.float32)
+    losses = np.zeros(5, np.float32)
+    dverts = np.zeros((N, V, 3), np.float32)
+    dtrans = np.zeros((N, 3), np.float32)
+    w = np.asarray(weights, np.float32)
+    assert shim.hm3_eval(V, len(faces), _p(faces), N, _p(lbs), _p(trans), _p(dfm), _p(pts), S, _p(w), _p(verts), _p(losses),
+                         _p(dverts), _p(dtrans)) == 0
+    tv = (torch.from_numpy(lbs).double() + torch.from_numpy(trans).double()[:, None, :] + torch.from_numpy(dfm).double())
+    assert np.abs(verts - tv.numpy()).max() < 1e-6
+    total, terms, g = mc.oracle_objective(verts, pts, faces, weights)       # differentiate at the float32 vertices
+    for i, k in enumerate(("chamfer", "edge", "normal", "laplacian")):
+        if k in terms:
+            assert abs(losses[i] - terms[k]) <= 2e-5 * abs(terms[k]), (k, losses[i], terms[k])
+    assert abs(losses[4] - total) <= 2e-5 * abs(total)
+    rel = np.linalg.norm(dverts - g) / np.linalg.norm(g)
+    assert rel < 2e-4, rel
+    assert np.abs(dtrans - g.sum(1)).max() <= 2e-4 * np.abs(g.sum(1)).max() + 1e-7
+
+
+def test_face_pair_clamped_branch_matches_oracle(shim):
+    """a mesh small enough that every pair falls under torch's cosine_similarity clamp"""
+    md, lbs, trans, dfm, pts = _problem(1, 64, seed=3, deform=False)
+    V, faces = md.num_verts, np.ascontiguousarray(md.faces, np.int32)
+    lbs = (lbs * 1e-3).astype(np.float32)
+    trans[:] = 0
+    w = np.array([0.0, 0.0, 1.0, 0.0], np.float32)
+    verts, losses = np.zeros((1, V, 3), np.float32), np.zeros(5, np.float32)
+    dverts, dtrans = np.zeros((1, V, 3), np.float32), np.zeros((1, 3), np.float32)
+    assert shim.hm3_eval(V, len(faces), _p(faces), 1, _p(lbs), _p(trans), None, _p(pts), 64, _p(w), _p(verts), _p(losses),
+                         _p(dverts), _p(dtrans)) == 0
+    tv = torch.from_numpy(verts).double().requires_grad_(True)
+    val = mo.normal_consistency(tv, mo.face_pairs(faces))
+    val.backward()
+    assert abs(losses[2] - float(val.detach())) < 2e-5 * abs(float(val.detach()))
+    g = tv.grad.numpy()
+    assert np.linalg.norm(dverts - g) / np.linalg.norm(g) < 2e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 3. sampler
+# ---------------------------------------------------------------------------------------------------------------
+def test_philox_known_answers(shim):
+    """Random123 known-answer vectors for philox4x32-10"""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        out = np.zeros(4, np.uint32)
+        shim.hm3_philox(_p(np.array(ctr, np.uint32)), _p(np.array(key, np.uint32)), _p(out))
+        assert tuple(int(x) for x in out) == want
+
+
+def test_sampler_distribution_and_determinism(shim):
+    md = synthetic.synthetic_model(seed=0, shape_family_id=1)
+    verts = np.ascontiguousarray(md.v_template, np.float32)
+    faces = np.ascontiguousarray(md.faces, np.int32)
+    V, F, S = len(verts), len(faces), 200000
+    pts, chosen = np.zeros((S, 3), np.float32), np.zeros(S, np.int32)
+    assert shim.hm3_sample(V, _p(verts), F, _p(faces), S, C.c_ulonglong(1234), 7, 0, _p(pts), _p(chosen)) == 0
+    area = mo.face_areas(verts, faces)
+    prob = area / area.sum()
+    # face frequencies follow the areas: chi-square over 40 groups of consecutive faces
+    groups = np.array_split(np.arange(F), 40)
+    obs = np.array([np.isin(chosen, g).sum() for g in groups], np.float64)
+    exp = np.array([prob[g].sum() for g in groups]) * S
+    chi2 = ((obs - exp) ** 2 / exp).sum()
+    assert chi2 < 80.0, chi2                                   # 39 dof: mean 39, 99.99th percentile ~ 77
+    # every sample lies in the plane and inside its triangle
+    a, b, c = verts[faces[chosen, 0]], verts[faces[chosen, 1]], verts[faces[chosen, 2]]
+    M = np.stack([b - a, c - a], axis=2).astype(np.float64)                       # (S,3,2)
+    sol = np.einsum("sij,sj->si", np.linalg.pinv(M), (pts - a).astype(np.float64))
+    assert sol.min() > -1e-3 and (sol.sum(1)).max() < 1 + 1e-3
+    resid = np.einsum("sij,sj->si", M, sol) - (pts - a)
+    assert np.abs(resid).max() < 1e-5
+    # barycentric weights uniform over the triangle: E[w1] = E[w2] = 1/3
+    assert abs(sol[:, 0].mean() - 1 / 3) < 5e-3 and abs(sol[:, 1].mean() - 1 / 3) < 5e-3
+    # same (seed, iteration, mesh) -> same points; any of them changed -> different points
+    p2, c2 = np.zeros((S, 3), np.float32), np.zeros(S, np.int32)
+    shim.hm3_sample(V, _p(verts), F, _p(faces), S, C.c_ulonglong(1234), 7, 0, _p(p2), _p(c2))
+    assert np.array_equal(pts, p2)
+    for seed, it, mesh in ((1235, 7, 0), (1234, 8, 0), (1234, 7, 1)):
+        shim.hm3_sample(V, _p(verts), F, _p(faces), S, C.c_ulonglong(seed), it, mesh, _p(p2), _p(c2))
+        assert (c2 != chosen).mean() > 0.9
+    # zero-area faces are never drawn, a mesh without area is rejected
+    vz = verts.copy()
+    fz = faces.copy()
+    fz[10] = [fz[10, 0], fz[10, 1], fz[10, 1]]
+    fz[F - 1] = [fz[F - 1, 0], fz[F - 1, 0], fz[F - 1, 1]]
+    shim.hm3_sample(V, _p(vz), F, _p(fz), S, C.c_ulonglong(99), 0, 0, _p(p2), _p(c2))
+    assert not np.isin(c2, [10, F - 1]).any()
+    assert shim.hm3_sample(V, _p(np.zeros_like(verts)), F, _p(faces), 8, C.c_ulonglong(1), 0, 0, _p(p2), _p(c2)) == 1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 4. host side of the fitter_3d drop-in (no GPU): .obj parsing, normalisation, schemes, figures
+# ---------------------------------------------------------------------------------------------------------------
+def test_load_obj_variants_and_normalisation(tmp_path):
+    from smalify_amd.fitter_3d import utils as u
+    p = tmp_path / "quad.obj"
+    p.write_text("# comment\nmtllib x.mtl\nv 0 0 0\nv 2 0 0 1.0\nv 2 1 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\n"
+                 "f 1/1/1 2/1/1 3/1/1 4/1/1\nv 1 2 3\nf -1 -5 -4\nf 1//1 2//1 5//1\n")
+    v, f = u.load_obj(str(p))
+    assert v.shape == (5, 3) and v.dtype == np.float32
+    # quad fan-triangulated (0,1,2),(0,2,3); negative indices relative to the vertices read so far
+    assert f.tolist() == [[0, 1, 2], [0, 2, 3], [4, 0, 1], [0, 1, 4]]
+    nv = u.normalise_verts(v)
+    assert np.abs(nv.mean(0)).max() < 1e-6 and abs(np.abs(nv).max() - 1.0) < 1e-6
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 9\n")
+    with pytest.raises(ValueError):
+        u.load_obj(str(bad))
+    empty = tmp_path / "empty.obj"
+    empty.write_text("# nothing\n")
+    with pytest.raises(ValueError):
+        u.load_obj(str(empty))
+
+
+def test_param_groups_match_reference_schemes():
+    from smalify_amd.fitter_3d.trainer import SMALParamGroup, default_weights
+
+    class Dummy:
+        pass
+    d = Dummy()
+    for n in ("global_rot", "joint_rot", "trans", "betas", "log_beta_scales", "deform_verts"):
+        setattr(d, n, n)
+    assert default_weights == dict(w_chamfer=1.0, w_edge=1.0, w_normal=0.01, w_laplacian=0.1)
+    assert SMALParamGroup(d, "init").names() == ["global_rot", "trans"]
+    assert SMALParamGroup(d, "pose").names() == ["global_rot", "trans", "joint_rot"]
+    assert SMALParamGroup(d, "deform").names() == ["deform_verts"]
+    groups = list(SMALParamGroup(d, "default", {"joint_rot": 0.005}))
+    assert [g["name"] for g in groups] == ["global_rot", "joint_rot", "trans", "betas", "log_beta_scales"]
+    assert groups[1]["lr"] == 0.005 and "lr" not in groups[0]
+    with pytest.raises(AssertionError):
+        SMALParamGroup(d, "smbld")
+
+
+def test_plot_meshes_writes_figures(tmp_path):
+    from smalify_amd.fitter_3d import utils as u
+    v = CUBE_V.astype(np.float32)
+    f = CUBE_F
+    u.plot_meshes([(v, f), (v * 0.5, f)], np.stack([v * 0.9, v * 0.4]), f, ["a", "b"], title="t", figtitle="fig",
+                  out_dir=str(tmp_path / "meshes"))
+    for name in ("a - t.png", "b - t.png"):
+        assert (tmp_path / "meshes" / name).stat().st_size > 1000
