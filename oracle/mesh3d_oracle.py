@@ -6,7 +6,7 @@ step of trainer.py:194 (default betas).  Only tests/ may import this file.
 PARITY UNPINNED: the four loss terms and the sampler live in PyTorch3D (pinned by the reference's README to v0.2.5,
 pytorch3d/loss/{chamfer,mesh_edge_loss,mesh_normal_consistency,mesh_laplacian_smoothing}.py and
 pytorch3d/ops/sample_points_from_meshes.py), which is absent from /root/reference and from this image.  What follows
-restates the published v0.2.5 algorithms; tests/test_mesh3d_oracle_cpu.py checks them against hand-derived closed forms
+restates the published v0.2.5 algorithms; tests/test_mesh3d_cpu.py checks them against hand-derived closed forms
 on small meshes.  The SMAL forward that feeds them (SMAL3DFitter.forward, trainer.py:94-108) is the LBS of
 smal_oracle.py, which IS pinned against the imported reference.
 
@@ -60,10 +60,11 @@ def face_pairs(faces):
 # ---------------------------------------------------------------------------------------------------------------
 def chamfer(points, verts):
     """pytorch3d.loss.chamfer_distance(points, verts)[0], v0.2.5 defaults"""
-    d2 = ((points[:, :, None, :] - verts[:, None, :, :]) ** 2).sum(-1)            # (N,S,V)
-    cham_x = d2.min(dim=2).values.mean(dim=1)
-    cham_y = d2.min(dim=1).values.mean(dim=1)
-    return (cham_x.sum() + cham_y.sum()) / verts.shape[0]
+    total = verts.sum() * 0.0
+    for n in range(verts.shape[0]):                                               # one mesh at a time: (S,V,3) temporaries
+        d2 = ((points[n, :, None, :] - verts[n, None, :, :]) ** 2).sum(-1)        # (S,V)
+        total = total + d2.min(dim=1).values.mean() + d2.min(dim=0).values.mean()
+    return total / verts.shape[0]
 
 
 def edge_loss(verts, edges):
