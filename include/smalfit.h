@@ -216,6 +216,42 @@ void smalfit_mesh_targets_destroy(smalfit_mesh_targets* targets);
 int smalfit_mesh_targets_sample(smalfit_mesh_targets* targets, void* stream, int num_points,
                                 unsigned long long seed, unsigned int iteration, float* points);
 
+/* ---- Stage.step in one call ------------------------------------------------------------------------------------
+ * replaces: one iteration of Stage.run                       reference fitter_3d/trainer.py:229-241,257-262
+ *   new_src_verts = smal_3d_fitter(); loss = forward(...); loss.backward(); optimizer.step()
+ * = SMAL forward on [global_rot | joint_rot], target points sampled (or taken from `points`), the four-term objective,
+ * its gradient back through the SMAL model, torch.optim.Adam on every parameter whose learning rate is > 0 (the
+ * parameter groups of trainer.py:113-119 with their custom learning rates) -- about 20 kernel launches, no host
+ * synchronisation.  All pointers are device pointers unless noted.  log_beta_scales is read, never trained
+ * (requires_grad=False in the reference, trainer.py:64-65). */
+typedef struct smalfit_fit3d_args {
+  int num_meshes;                  /* N */
+  int num_betas;                   /* columns of betas (20) */
+  int num_points;                  /* S target points per mesh (3000 in the reference) */
+  float* betas;                    /* (N,num_betas) */
+  const float* log_beta_scales;    /* (N,6) or NULL */
+  float* global_rot;               /* (N,3) */
+  float* joint_rot;                /* (N,34,3) */
+  float* trans;                    /* (N,3) */
+  float* deform_verts;             /* (N,V,3) or NULL (then treated as zero and not trainable) */
+  /* Adam: learning rate per parameter (<= 0: frozen in this stage) and its state (exp_avg, exp_avg_sq), same shapes */
+  float lr_betas, lr_global_rot, lr_joint_rot, lr_trans, lr_deform_verts;
+  float *m_betas, *v_betas, *m_global_rot, *v_global_rot, *m_joint_rot, *v_joint_rot, *m_trans, *v_trans,
+        *m_deform_verts, *v_deform_verts;
+  float beta1, beta2, eps;         /* torch defaults 0.9, 0.999, 1e-8 (trainer.py:194) */
+  int adam_t;                      /* 1-based step count of this stage's optimiser */
+  float weights[4];                /* w_chamfer, w_edge, w_normal, w_laplacian; <= 0 skips the term */
+  const float* points;             /* (N,S,3) target points, or NULL: sample them from the target meshes */
+  unsigned long long seed;         /* sampler key and counter, see smalfit_mesh_targets_sample */
+  unsigned int iteration;
+  float* points_out;               /* optional (N,S,3): the target points this step used */
+  float* losses;                   /* (5): chamfer, edge, normal, laplacian, weighted total -- before the update */
+  float* verts_out;                /* optional (N,V,3): the vertices the loss was evaluated at */
+} smalfit_fit3d_args;
+/* `targets` may be NULL when args->points is given or w_chamfer <= 0 */
+int smalfit_fit3d_step(smalfit_engine* engine, smalfit_mesh_objective* objective, smalfit_mesh_targets* targets,
+                       void* stream, const smalfit_fit3d_args* args);
+
 /* ---- torch.optim.Adam.step -----------------------------------------------------------------------
  * replaces: torch.optim.Adam(lr, betas=(0.5, 0.999)).step()  reference smal_fitter/optimize_to_joints.py:96,137
  * t = 1-based step count; eps outside the bias-corrected sqrt, as torch does */

@@ -43,6 +43,22 @@ class FitArgs(C.Structure):
                 ("verts_out", C.c_void_p)]
 
 
+class Fit3dArgs(C.Structure):
+    _fields_ = [("num_meshes", C.c_int), ("num_betas", C.c_int), ("num_points", C.c_int),
+                ("betas", C.c_void_p), ("log_beta_scales", C.c_void_p), ("global_rot", C.c_void_p),
+                ("joint_rot", C.c_void_p), ("trans", C.c_void_p), ("deform_verts", C.c_void_p),
+                ("lr_betas", C.c_float), ("lr_global_rot", C.c_float), ("lr_joint_rot", C.c_float),
+                ("lr_trans", C.c_float), ("lr_deform_verts", C.c_float),
+                ("m_betas", C.c_void_p), ("v_betas", C.c_void_p), ("m_global_rot", C.c_void_p),
+                ("v_global_rot", C.c_void_p), ("m_joint_rot", C.c_void_p), ("v_joint_rot", C.c_void_p),
+                ("m_trans", C.c_void_p), ("v_trans", C.c_void_p), ("m_deform_verts", C.c_void_p),
+                ("v_deform_verts", C.c_void_p),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("adam_t", C.c_int),
+                ("weights", C.c_float * 4), ("points", C.c_void_p), ("seed", C.c_ulonglong),
+                ("iteration", C.c_uint), ("points_out", C.c_void_p), ("losses", C.c_void_p),
+                ("verts_out", C.c_void_p)]
+
+
 # every symbol include/smalfit.h declares: (restype, argtypes)
 _VP, _I, _F = C.c_void_p, C.c_int, C.c_float
 SIGNATURES = {
@@ -78,6 +94,7 @@ SIGNATURES = {
     "smalfit_mesh_targets_create": (_I, [_I, _VP, _VP, _VP, _VP, C.POINTER(_VP)]),
     "smalfit_mesh_targets_destroy": (None, [_VP]),
     "smalfit_mesh_targets_sample": (_I, [_VP, _VP, _I, C.c_ulonglong, C.c_uint, _VP]),
+    "smalfit_fit3d_step": (_I, [_VP, _VP, _VP, _VP, C.POINTER(Fit3dArgs)]),
 }
 
 

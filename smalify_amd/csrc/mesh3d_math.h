@@ -65,23 +65,33 @@ SMALFIT_HD void barycentric_sample(const float* a, const float* b, const float* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// chamfer: nearest neighbour scan over p[3*begin .. 3*end) (interleaved xyz); strict '<' over ascending indices keeps
-// the lowest index among equal distances.  If `owner` is given, also accumulates sum (q - p_j) over the j with
-// owner[j] == self: the reverse-direction gradient gathered at the vertex instead of scattered from the points.
+// chamfer: nearest neighbour scan over the staged points p[begin .. end) (16-byte records: one LDS read per point);
+// strict '<' over ascending indices keeps the lowest index among equal distances.  With OWNER the record also carries
+// the index of the vertex that point chose in the other direction, and the scan accumulates sum (q - p_j) over the j
+// with owner == self: the reverse-direction gradient gathered at the vertex instead of scattered from the points.
 // ------------------------------------------------------------------------------------------------
-SMALFIT_HD void nearest_scan(float qx, float qy, float qz, const float* p, int begin, int end, int index_base,
-                             float& best, int& best_idx, const int* owner, int self, float g[3]) {
+struct alignas(16) ScanPoint {
+  float x, y, z;
+  int owner;
+};
+
+template <bool OWNER>
+SMALFIT_HD void nearest_scan(float qx, float qy, float qz, const ScanPoint* p, int begin, int end, int index_base,
+                             float& best, int& best_idx, int self, float g[3]) {
+#pragma unroll 4
   for (int j = begin; j < end; ++j) {
-    const float dx = qx - p[3 * j], dy = qy - p[3 * j + 1], dz = qz - p[3 * j + 2];
+    const ScanPoint s = p[j];
+    const float dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
     const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     if (d2 < best) {
       best = d2;
       best_idx = index_base + j;
     }
-    if (owner != nullptr && owner[j] == self) {
-      g[0] += dx;
-      g[1] += dy;
-      g[2] += dz;
+    if (OWNER) {
+      const float mk = s.owner == self ? 1.0f : 0.0f;   // branch-free: g + 1 * d and g + 0 * d are exact
+      g[0] = fmaf(mk, dx, g[0]);
+      g[1] = fmaf(mk, dy, g[1]);
+      g[2] = fmaf(mk, dz, g[2]);
     }
   }
 }

@@ -4,10 +4,12 @@ What stays identical: constructor arguments, parameter names and shapes, the fiv
 (trainer.py:113-119), per-parameter learning rates, one fresh Adam per Stage (trainer.py:194, default betas), the loss
 weights and their defaults (trainer.py:31), the .npz written by Stage.save_npz (trainer.py:264-279).
 
-What is different underneath: one Stage.step is five C-ABI calls on the current HIP stream -- smalfit_lbs_forward,
-smalfit_mesh_targets_sample, smalfit_mesh_objective_eval (all four terms + d/dverts + d/dtrans),
-smalfit_lbs_backward, smalfit_adam_step per trained parameter -- with no autograd graph and no host synchronisation;
-the loss history stays on the device until it is plotted or printed.  The target points are drawn by a counter-based
+What is different underneath: one Stage.step is ONE C-ABI call on the current HIP stream (smalfit_fit3d_step: SMAL
+forward, target-point sampling, all four loss terms, the gradient back through the SMAL model, Adam on the scheme's
+parameters -- about 20 kernel launches) with no autograd graph and no host synchronisation; the loss history stays on
+the device until it is plotted or printed.  Stage.evaluate / Stage.step_unfused compose the same iteration from the
+component entry points (smalfit_lbs_forward, smalfit_mesh_targets_sample, smalfit_mesh_objective_eval,
+smalfit_lbs_backward, smalfit_adam_step) and expose the gradients.  The target points are drawn by a counter-based
 generator keyed by (seed, global iteration), not by torch's global generator, so runs are reproducible.
 
 Two reference quirks kept on purpose: log_beta_scales sits in the parameter groups but has requires_grad=False, so no
@@ -16,18 +18,20 @@ CPU path (on its CUDA path `nn.Parameter(...).to(device)` yields a non-leaf tens
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 
 import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import config, engine as eng, model_io, runtime
+from .. import _lib, config, engine as eng, model_io, runtime
 from ..smal_model.smal_torch import SMAL
 
 default_weights = dict(w_chamfer=1.0, w_edge=1.0, w_normal=0.01, w_laplacian=0.1)     # trainer.py:31
 _WEIGHT_ORDER = ("w_chamfer", "w_edge", "w_normal", "w_laplacian")
 N_SAMPLE_POINTS = 3000                                                                 # trainer.py:209
+_PARAM_ORDER = ("betas", "log_beta_scales", "global_rot", "joint_rot", "trans", "deform_verts")
 
 
 class SMAL3DFitter(nn.Module):
@@ -144,7 +148,7 @@ class Stage:
         for g in self.param_group:
             p = g["params"][0]
             if p.requires_grad:
-                self._adam[g["name"]] = dict(lr=float(g.get("lr", self.lr)), t=0, m=torch.zeros_like(p), v=torch.zeros_like(p))
+                self._adam[g["name"]] = dict(lr=float(g.get("lr", self.lr)), m=torch.zeros_like(p), v=torch.zeros_like(p))
         fit = smal_3d_fitter
         V = int(fit.smal_model.v_template.shape[0])
         self.n_verts = V
@@ -157,6 +161,8 @@ class Stage:
         self.iteration_offset = int(iteration_offset)      # global iteration of this stage's first step (StageManager)
         self._loss_history = torch.zeros(max(self.n_it, 1), device=self.device)
         self._done = 0
+        self._t = 0              # Adam step count of this stage
+        self._args = None        # smalfit_fit3d_args, built on the first step
         self.consider_loss = lambda loss_name: self.loss_weights[f"w_{loss_name}"] > 0
 
     # ---- evaluation ----------------------------------------------------------------------------------------------
@@ -202,16 +208,60 @@ class Stage:
         return self.evaluate(self._done)[0]
 
     def step(self, epoch):
-        """one iteration: loss, gradients, Adam on the parameters of the scheme (trainer.py:229-241)"""
+        """one iteration (trainer.py:229-241): loss, gradients and Adam on the parameters of the scheme in ONE C-ABI
+        call (smalfit_fit3d_step).  Returns the total loss before the update (device scalar)."""
+        fit = self.smal_3d_fitter
+        e = fit._engine()
+        a = self._step_args()
+        for name in _PARAM_ORDER:
+            setattr(a, name, getattr(fit, name).data_ptr())
+        a.weights = (C.c_float * 4)(*self._weights())
+        a.iteration = (self.iteration_offset + int(epoch)) & 0xFFFFFFFF
+        self._t += 1
+        a.adam_t = self._t
+        dev_targets = getattr(self.target_meshes, "_dev", self.target_meshes)
+        eng.check(e.lib.smalfit_fit3d_step(e.handle, self._objective.handle, dev_targets.handle, eng._stream(), C.byref(a)),
+                  "smalfit_fit3d_step")
+        return self._buffers["losses"][4]
+
+    def step_unfused(self, epoch):
+        """the same iteration as five separate C-ABI calls + one smalfit_adam_step per parameter; leaves the gradients
+        in `.grad` of the trained parameters (development / inspection path, ~3x the host time of step())"""
         loss, grads = self.evaluate(epoch)
         fit = self.smal_3d_fitter
+        self._t += 1
         for name, st in self._adam.items():
             p = getattr(fit, name)
             g = grads[name]
             p.grad = g
-            st["t"] += 1
-            eng.adam_step(p.data, g, st["m"], st["v"], st["lr"], st["t"], beta1=0.9, beta2=0.999, eps=1e-8)
+            eng.adam_step(p.data, g, st["m"], st["v"], st["lr"], self._t, beta1=0.9, beta2=0.999, eps=1e-8)
         return loss
+
+    def _step_args(self):
+        if self._args is None:
+            fit = self.smal_3d_fitter
+            N = fit.batch_size
+            a = _lib.Fit3dArgs()
+            a.num_meshes, a.num_betas, a.num_points = N, int(fit.betas.shape[1]), N_SAMPLE_POINTS
+            for name in _PARAM_ORDER:
+                if name == "log_beta_scales":          # read by the forward, never trained (trainer.py:64-65)
+                    continue
+                st = self._adam.get(name)
+                setattr(a, "lr_" + name, st["lr"] if st else 0.0)
+                setattr(a, "m_" + name, st["m"].data_ptr() if st else None)
+                setattr(a, "v_" + name, st["v"].data_ptr() if st else None)
+            a.beta1, a.beta2, a.eps = 0.9, 0.999, 1e-8
+            a.points = None
+            a.seed = self.seed & (2 ** 64 - 1)
+            if self._points is None:
+                self._points = torch.empty(N, N_SAMPLE_POINTS, 3, device=self.device)
+            if "losses" not in self._buffers:
+                self._buffers["losses"] = torch.zeros(5, device=self.device)
+            a.points_out = self._points.data_ptr()
+            a.losses = self._buffers["losses"].data_ptr()
+            a.verts_out = None
+            self._args = a
+        return self._args
 
     def run(self, plot=False, progress=True, report_every=50):
         """Run the entire Stage (trainer.py:257-270).  The description line is refreshed every `report_every`

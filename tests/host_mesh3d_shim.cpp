@@ -26,13 +26,20 @@ void chamfer_query(const float q[3], const float* others, int no, const int* own
     si[w] = 0x7fffffff;
     sg[w][0] = sg[w][1] = sg[w][2] = 0.f;
   }
+  std::vector<ScanPoint> sp(kChunk);
   for (int base = 0; base < no; base += kChunk) {
     const int cnt = std::min(kChunk, no - base);
+    for (int i = 0; i < cnt; ++i) {
+      sp[i].x = others[3 * (size_t)(base + i)];
+      sp[i].y = others[3 * (size_t)(base + i) + 1];
+      sp[i].z = others[3 * (size_t)(base + i) + 2];
+      sp[i].owner = owner ? owner[base + i] : 0;
+    }
     const int per = (cnt + 3) >> 2;
     for (int w = 0; w < kSlices; ++w) {
       const int b = std::min(w * per, cnt), e = std::min(b + per, cnt);
-      nearest_scan(q[0], q[1], q[2], others + 3 * (size_t)base, b, e, base, sb[w], si[w], owner ? owner + base : nullptr,
-                   self, sg[w]);
+      if (owner) nearest_scan<true>(q[0], q[1], q[2], sp.data(), b, e, base, sb[w], si[w], self, sg[w]);
+      else nearest_scan<false>(q[0], q[1], q[2], sp.data(), b, e, base, sb[w], si[w], self, sg[w]);
     }
   }
   best = sb[0];

@@ -29,3 +29,27 @@ def test_missing_device_fails_loudly():
     import pytest
     with pytest.raises(eng.SmalfitError):
         eng.DeviceModel(synthetic.synthetic_model())
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """every struct the binding passes by pointer has the layout gcc gives the declaration in include/smalfit.h:
+    same field names, offsets and total size (guards against the ctypes mirror drifting from the header)"""
+    import ctypes as C
+    import subprocess
+    pairs = {"smalfit_model_desc": _lib.ModelDesc, "smalfit_fit_args": _lib.FitArgs, "smalfit_fit3d_args": _lib.Fit3dArgs}
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "smalfit.h"', "int main(void) {"]
+    for cname, cls in pairs.items():
+        lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for field, _ in cls._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, field, cname, field))
+    lines += ["return 0; }"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.dirname(HEADER), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    got = {(a, b): int(c) for a, b, c in (ln.split() for ln in out.strip().splitlines())}
+    for cname, cls in pairs.items():
+        assert got[(cname, "sizeof")] == C.sizeof(cls), cname
+        for field, _ in cls._fields_:
+            assert got[(cname, field)] == getattr(cls, field).offset, (cname, field)
