@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run every HIP-vs-oracle parity case and print the error metrics (no assertions).
-Usage on the GPU box:  python tools/gpu_diag.py [> gpurun_out/diag.txt]"""
+Usage on the GPU box:  python tests/gpu_diag.py [> gpurun_out/diag.txt]"""
 import os
 import sys
 import time

@@ -1,4 +1,4 @@
-"""Parity cases HIP-vs-oracle, shared by tests/test_gpu_parity.py (asserting) and tools/gpu_diag.py
+"""Parity cases HIP-vs-oracle, shared by tests/test_gpu_parity.py (asserting) and tests/gpu_diag.py
 (printing).  Every function returns {metric_name: value}; nothing here asserts.
 
 Oracle = oracle/smal_oracle.py in float64 (test infrastructure).  HIP = smalify_amd through the C-ABI.
