@@ -17,7 +17,12 @@ def test_every_declared_symbol_is_exported_and_bound():
     for name in sorted(declared):
         assert hasattr(lib, name), name
     # every bound signature is declared in the header (no private entry points in the binding)
-    assert set(_lib.SIGNATURES) <= declared | {"smalfit_debug_set"}
+    assert set(_lib.SIGNATURES) <= declared
+    # ... and the product exports nothing else: no developer switches, no undeclared entry points
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("smalfit_")}
+    assert exported == declared, exported ^ declared
     assert lib.smalfit_version() >= 1
 
 

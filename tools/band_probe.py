@@ -1,5 +1,7 @@
 """Developer probe: per-stage hit rates of the rasteriser's depth-bound cache and section times (GPU box).
-usage: python tools/band_probe.py [steps] [scene]"""
+usage: python tools/band_probe.py [steps] [scene]
+Needs a developer build of the library (the product compiles the probes out):
+    tools/build_variant.sh probes -DSMALFIT_DEV_PROBES && SMALFIT_LIB=$PWD/smalify_amd/_variants/probes.so python tools/band_probe.py ..."""
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
