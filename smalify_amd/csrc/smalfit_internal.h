@@ -76,7 +76,7 @@ struct AssembleArgs {
   const float* dbeta_part;
   const float* dJrest;
   const float* dbetaJ;     // [M][NBall] d beta through the rest joints (chain_bwd_kernel)
-  int ngrp_beta;           // frame groups of dbeta_kernel
+  int ngrp_beta;           // frame groups of the shape-blend adjoint (dbeta_block)
   const float* JS;
   const float* gb_prior;
   const float* gls_prior;
