@@ -6,7 +6,6 @@ Tolerances (float32 engine vs float64 oracle, stated per the north-star's 1e-4 r
   silhouette: max abs 2e-3 and < 0.5 % of pixels off by more than 1e-4 (a pixel/face pair exactly at the
   blur cut-off or at the K-th depth flips a 1e-4-sized contribution), silhouette gradients 1e-2 rel-L2.
 """
-import numpy as np
 import pytest
 import torch
 

@@ -1,7 +1,7 @@
 """Developer probe: time smalfit_fit_eval sections under different debug flags / scenes (GPU box).
 Needs a developer build of the library (the product compiles the probes out):
     tools/build_variant.sh probes -DSMALFIT_DEV_PROBES && SMALFIT_LIB=$PWD/smalify_amd/_variants/probes.so python tools/raster_probe.py ..."""
-import ctypes, json, os, sys, time
+import ctypes, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
 import bench
