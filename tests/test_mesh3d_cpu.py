@@ -291,3 +291,39 @@ def test_plot_meshes_writes_figures(tmp_path):
                   out_dir=str(tmp_path / "meshes"))
     for name in ("a - t.png", "b - t.png"):
         assert (tmp_path / "meshes" / name).stat().st_size > 1000
+
+
+def test_open_and_non_manifold_meshes_match_oracle(shim):
+    """boundary edges (one face: no pair), an edge shared by three faces (three pairs), an isolated vertex (empty ring):
+    the gather tables and the maths against the oracle on a mesh small enough to enumerate by hand"""
+    rs = np.random.RandomState(8)
+    #   strip of 4 triangles 0-1-2-3-4-5, a fin (1,2,6) on the edge (1,2) shared by two strip faces, vertex 7 isolated
+    faces = np.array([[0, 1, 2], [2, 1, 3], [2, 3, 4], [4, 3, 5], [1, 2, 6]], np.int32)
+    V = 8
+    E, P, nbr_off, nbr, pairs, inc_off, inc = _shim_topology(shim, V, faces)
+    assert E == 11 and P == 5                       # edge (1,2): 3 faces -> 3 pairs; (2,3) and (3,4): 1 pair each
+    assert nbr_off[8] - nbr_off[7] == 0             # isolated vertex
+    assert sorted(map(tuple, pairs[:, :2].tolist())) == [(1, 2), (1, 2), (1, 2), (2, 3), (3, 4)]
+    N, S = 2, 9
+    lbs = rs.randn(N, V, 3).astype(np.float32)
+    trans = rs.randn(N, 3).astype(np.float32)
+    pts = rs.randn(N, S, 3).astype(np.float32)
+    w = np.array([1.0, 0.7, 0.4, 0.2], np.float32)
+    verts, losses = np.zeros((N, V, 3), np.float32), np.zeros(5, np.float32)
+    dverts, dtrans = np.zeros((N, V, 3), np.float32), np.zeros((N, 3), np.float32)
+    assert shim.hm3_eval(V, len(faces), _p(faces), N, _p(lbs), _p(trans), None, _p(pts), S, _p(w), _p(verts), _p(losses),
+                         _p(dverts), _p(dtrans)) == 0
+    total, terms, g = mc.oracle_objective(verts, pts, faces, tuple(float(x) for x in w))
+    for i, k in enumerate(("chamfer", "edge", "normal", "laplacian")):
+        assert abs(losses[i] - terms[k]) <= 2e-5 * abs(terms[k]), (k, losses[i], terms[k])
+    assert abs(losses[4] - total) <= 2e-5 * abs(total)
+    assert np.linalg.norm(dverts - g) / np.linalg.norm(g) < 2e-5
+    # coincident vertices: zero-length edge, zero Laplacian residual -> finite gradients (torch's subgradient 0 at the origin)
+    flat = np.zeros((1, V, 3), np.float32)
+    z3 = np.zeros((1, 3), np.float32)
+    v1, l1 = np.zeros((1, V, 3), np.float32), np.zeros(5, np.float32)
+    d1, t1 = np.zeros((1, V, 3), np.float32), np.zeros((1, 3), np.float32)
+    w2 = np.array([0.0, 1.0, 1.0, 1.0], np.float32)
+    assert shim.hm3_eval(V, len(faces), _p(faces), 1, _p(flat), _p(z3), None, _p(pts), S, _p(w2), _p(v1), _p(l1), _p(d1), _p(t1)) == 0
+    assert np.isfinite(l1).all() and np.isfinite(d1).all()
+    assert l1[1] == 0.0 and l1[3] == 0.0 and abs(l1[2] - 1.0) < 1e-6      # degenerate normals: cos = 0 under the clamp
