@@ -14,6 +14,10 @@ One process per GPU (python -m torch.distributed.run ... bench.py --gpus N): fra
 contiguously across ranks (strong scaling), see smalify_amd/distributed.py.
 
 Prints ONE JSON line on rank 0.
+
+SMALFIT_BENCH_FORCE_DIST=1 (validation hook): initialise the process group and run the sharded step with its
+all-gather even when WORLD_SIZE is 1, so that the RCCL path can be exercised on a single-GPU box
+(python -m torch.distributed.run --nproc-per-node 1 ... bench.py).
 """
 import argparse
 import json
@@ -127,7 +131,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (smalify_amd has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = os.environ.get("SMALFIT_BENCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or force_dist
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     md = synthetic.synthetic_model(seed=0, shape_family_id=1)
@@ -148,7 +154,7 @@ def main():
     def new_fitter():
         f = fit.FusedFitter(engine, tj[lo:hi], vis[lo:hi], tsil[lo:hi], WINDOW, use_unity_prior=True,
                             mean_betas=shape_prior[1][:20], mean_log_scales=shape_prior[1][20:26])
-        return distributed.ShardedFitter(f, rank, world) if world > 1 else f
+        return distributed.ShardedFitter(f, rank, world, always_exchange=force_dist) if use_dist else f
 
     W = np.array(config.OPT_WEIGHTS).T
 
@@ -163,7 +169,7 @@ def main():
                 stage_seconds.append(time.perf_counter() - t_stage)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -171,7 +177,7 @@ def main():
     run(new_fitter(), scaled_schedule(max(args.warmup, 4)))
     fitter = new_fitter()
     sched = scaled_schedule(args.steps)
-    base = fitter.fitter if world > 1 else fitter
+    base = fitter.fitter if use_dist else fitter
     # HIP events on the launch stream inside the timed region, on every 8th iteration (an event record costs ~5 us
     # of stream time; all sections of every iteration would slow the measured loop by ~8 %)
     base.e.profile_begin(args.steps, PROFILE_STRIDE)
@@ -181,7 +187,7 @@ def main():
     run(fitter, sched, stage_seconds)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -231,7 +237,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(md, pose_prior, shape_prior, tj.cpu().numpy(), vis.cpu().numpy(),
                                                tsil.cpu().numpy(), W[2][:6], float(W[2][6]))
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -41,9 +41,11 @@ class ShardedFitter:
     """Wraps a local fitter (FusedFitter protocol: evaluate / apply_adam / shared_grad / boundary_records /
     halo_prev / halo_next / trainable / begin_stage / losses) for rank `rank` of `world_size`."""
 
-    def __init__(self, local_fitter, rank, world_size, group=None):
+    def __init__(self, local_fitter, rank, world_size, group=None, always_exchange=False):
+        """always_exchange: run the collective even when world_size == 1 (exercises the RCCL plumbing on a single GPU)"""
         self.fitter = local_fitter
         self.rank, self.world, self.group = rank, world_size, group
+        self.always_exchange = bool(always_exchange)
         self._gather = None
         self._halo_valid = False
 
@@ -71,7 +73,7 @@ class ShardedFitter:
     def step(self, weights, w_temp, lr, stage_id):
         f = self.fitter
         names = f.trainable(stage_id)
-        if self.world == 1:
+        if self.world == 1 and not self.always_exchange:
             f.evaluate(weights, w_temp, stage_id, want=names)
             f.apply_adam(names, lr)
             return f.losses
