@@ -121,6 +121,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout must carry exactly one JSON line: libraries write there too (RCCL prints a version banner when the
+    # communicator is created), so file descriptor 1 points at stderr for the whole run and the line goes to the saved one
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from smalify_amd import config, distributed, engine as eng, fitter as fit, synthetic
@@ -236,9 +242,13 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(md, pose_prior, shape_prior, tj.cpu().numpy(), vis.cpu().numpy(),
                                                tsil.cpu().numpy(), W[2][:6], float(W[2][6]))
-        print(json.dumps(out))
+        line = json.dumps(out)
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:                       # the JSON line is the last thing this process writes
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os.write(json_fd, (line + "\n").encode())
 
 
 if __name__ == "__main__":
