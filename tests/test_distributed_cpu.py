@@ -177,3 +177,31 @@ def test_shard_range_validation():
         distributed.shard_range(64, 0, 3)
     with pytest.raises(ValueError):
         distributed.shard_range(64, 0, 8, window=16)
+
+
+def test_world_of_one_with_the_collective_equals_the_plain_step():
+    """ShardedFitter(always_exchange=True) on a world of one (bench.py's SMALFIT_BENCH_FORCE_DIST hook: the collective
+    runs, there are no neighbours) must reproduce the short-cut path bit for bit"""
+    sys.path.insert(0, ROOT)
+    from smalify_amd import config as cfg, distributed
+    torch.set_num_threads(2)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(31500 + (os.getpid() % 2000)))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        W = np.array(cfg.OPT_WEIGHTS).T
+        w1 = W[1][:6].copy()
+        w1[1] = 0.0
+        out = []
+        for always in (False, True):
+            prob, params = _problem()
+            f = distributed.ShardedFitter(OracleLocalFitter(prob, params, 0, prob.N, 2), 0, 1, always_exchange=always)
+            for stage_id, its in ((0, 2), (1, 2)):
+                f.begin_stage(stage_id)
+                for _ in range(its):
+                    f.step(W[0][:6] if stage_id == 0 else w1, float(W[stage_id][6]), float(W[stage_id][8]), stage_id)
+            assert (f.fitter.halo_prev is None) and (f.fitter.halo_next is None)
+            out.append({k: v.numpy().copy() for k, v in f.fitter.p.items()})
+        for k in out[0]:
+            assert np.array_equal(out[0][k], out[1][k]), k
+    finally:
+        dist.destroy_process_group()
