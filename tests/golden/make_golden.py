@@ -57,6 +57,8 @@ def _euler2angle_axis(z=0, y=0, x=0):
     m = (Rotation.from_euler("x", x) * Rotation.from_euler("y", y) * Rotation.from_euler("z", z))   # nibabel: Rx Ry Rz
     rv = m.as_rotvec()
     ang = np.linalg.norm(rv)
+    if ang == 0.0:                      # nibabel's quat2angle_axis returns the x axis for the identity
+        return 0.0, np.array([1.0, 0.0, 0.0])
     return ang, rv / ang
 
 

@@ -163,6 +163,23 @@ def test_stage_loop_follows_the_oracle(scheme, lr, custom_lrs, iters):
             assert np.array_equal(getattr(fit, k).detach().cpu().numpy(), params[k].float().numpy()), k
 
 
+def test_fitter_matches_the_reference_golden():
+    """SMAL3DFitter against outputs of the reference's own class (tests/golden/make_golden_fit3d.py): initial
+    parameters, requires_grad flags, and forward() = SMAL(...) + trans + deform_verts at perturbed parameters"""
+    z = np.load(os.path.join(HERE, "golden", "reference_golden_fit3d.npz"), allow_pickle=True)
+    names = ("betas", "log_beta_scales", "global_rot", "joint_rot", "trans", "deform_verts")
+    md, fit, _ = _fitter(2)
+    for k in names:
+        assert np.array_equal(getattr(fit, k).detach().cpu().numpy(), z["init_" + k]), k
+    assert [int(getattr(fit, k).requires_grad) for k in names] == z["requires_grad"].tolist()
+    vsel = z["vsel"]
+    assert mc.rel(fit().cpu().numpy()[:, vsel], z["init_verts"]) < 2e-6
+    with torch.no_grad():
+        for k in names:
+            getattr(fit, k).copy_(torch.from_numpy(z["p_" + k]).cuda())
+    assert mc.rel(fit().cpu().numpy()[:, vsel], z["p_verts"]) < 2e-6
+
+
 def test_fused_step_equals_the_component_calls():
     """smalfit_fit3d_step against the same iteration composed from smalfit_lbs_forward / mesh_targets_sample /
     mesh_objective_eval / lbs_backward / adam_step: same kernels on the same inputs -> same bits, except that the fused

@@ -327,3 +327,63 @@ def test_open_and_non_manifold_meshes_match_oracle(shim):
     assert shim.hm3_eval(V, len(faces), _p(faces), 1, _p(flat), _p(z3), None, _p(pts), S, _p(w2), _p(v1), _p(l1), _p(d1), _p(t1)) == 0
     assert np.isfinite(l1).all() and np.isfinite(d1).all()
     assert l1[1] == 0.0 and l1[3] == 0.0 and abs(l1[2] - 1.0) < 1e-6      # degenerate normals: cos = 0 under the clamp
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 5. what the reference's own fitter_3d code produces without PyTorch3D (tests/golden/make_golden_fit3d.py):
+#    SMAL3DFitter.forward and the optimiser semantics of a Stage pin the oracle the GPU tests compare against
+# ---------------------------------------------------------------------------------------------------------------
+GOLDEN_FIT3D = os.path.join(HERE, "golden", "reference_golden_fit3d.npz")
+_PARAMS = ("betas", "log_beta_scales", "global_rot", "joint_rot", "trans", "deform_verts")
+
+
+def _oracle_model_family_minus1():
+    from oracle import smal_oracle as so
+    return so.OracleModel(synthetic.synthetic_model(seed=0, shape_family_id=-1))
+
+
+def test_fitter_forward_matches_reference_golden():
+    z = np.load(GOLDEN_FIT3D, allow_pickle=True)
+    om = _oracle_model_family_minus1()
+    # initial values: betas = mean of the LAST shape cluster (index -1), everything else zero (trainer.py:56-76)
+    sd = mc.synthetic_smal_data()
+    assert np.allclose(z["init_betas"], np.tile(np.asarray(sd["cluster_means"])[-1][:20], (2, 1)), atol=1e-7)
+    for k in _PARAMS[1:]:
+        assert np.all(z["init_" + k] == 0), k
+    assert z["requires_grad"].tolist() == [1, 0, 1, 1, 1, 1]                # log_beta_scales frozen
+    assert z["default_weights"].tolist() == [mo.DEFAULT_WEIGHTS[k] for k in ("w_chamfer", "w_edge", "w_normal", "w_laplacian")]
+    vsel = z["vsel"]
+    for tag in ("init", "p"):
+        params = {k: torch.from_numpy(z[tag + "_" + k]).double() for k in _PARAMS}
+        verts = mo.fitter_verts(om, params).numpy()[:, vsel]
+        assert mc.rel(verts, z[tag + "_verts"]) < 2e-6, tag
+
+
+@pytest.mark.parametrize("scheme,lr,custom", [("default", 0.01, {"joint_rot": 0.005}), ("init", 0.05, None),
+                                              ("deform", 2e-4, None)])
+def test_stage_optimiser_semantics_match_reference_golden(scheme, lr, custom):
+    """SMALParamGroup + torch.optim.Adam(lr) of the reference, 6 steps on a stand-in loss (mean squared distance to a
+    fixed target): which parameters move, with which learning rate, default betas -- against the oracle's Adam"""
+    from smalify_amd.fitter_3d.trainer import SMALParamGroup
+    z = np.load(GOLDEN_FIT3D, allow_pickle=True)
+    for name in ("default", "init", "shape", "pose", "deform"):
+        assert SMALParamGroup.param_map[name] == z["param_map_" + name].tolist()
+    om = _oracle_model_family_minus1()
+    target = torch.from_numpy(z["adam_target"]).double()
+    params = {k: torch.from_numpy(z["p_" + k]).double() for k in _PARAMS}
+    names = [n for n in SMALParamGroup.param_map[scheme] if n != "log_beta_scales"]
+    adam = mo.Adam({n: (custom or {}).get(n, lr) for n in names})
+    hist = []
+    for _ in range(6):
+        leaf = {k: v.clone().requires_grad_(k in names) for k, v in params.items()}
+        loss = ((mo.fitter_verts(om, leaf) - target) ** 2).sum(-1).mean()
+        grads = dict(zip(names, torch.autograd.grad(loss, [leaf[n] for n in names])))
+        adam.step(params, grads)
+        hist.append(float(loss.detach()))
+    assert np.allclose(hist, z["adam_%s_loss" % scheme], rtol=2e-4)
+    for k in _PARAMS:
+        got, want = params[k].numpy(), z["adam_%s_%s" % (scheme, k)]
+        if k in names:
+            assert mc.rel(got, want) < (2e-3 if k == "deform_verts" else 2e-4), (k, mc.rel(got, want))
+        else:
+            assert np.array_equal(got.astype(np.float32), z["p_" + k]) and np.array_equal(want, z["p_" + k]), k
