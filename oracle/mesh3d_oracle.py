@@ -7,8 +7,10 @@ PARITY UNPINNED: the four loss terms and the sampler live in PyTorch3D (pinned b
 pytorch3d/loss/{chamfer,mesh_edge_loss,mesh_normal_consistency,mesh_laplacian_smoothing}.py and
 pytorch3d/ops/sample_points_from_meshes.py), which is absent from /root/reference and from this image.  What follows
 restates the published v0.2.5 algorithms; tests/test_mesh3d_cpu.py checks them against hand-derived closed forms
-on small meshes.  The SMAL forward that feeds them (SMAL3DFitter.forward, trainer.py:94-108) is the LBS of
-smal_oracle.py, which IS pinned against the imported reference.
+on small meshes.  PINNED against the imported reference (tests/golden/make_golden_fit3d.py ->
+tests/golden/reference_golden_fit3d.npz, checked in tests/test_mesh3d_cpu.py): fitter_verts (SMAL3DFitter.forward,
+trainer.py:94-108: the LBS of smal_oracle.py + trans + deform_verts) and Adam over the parameter groups of a Stage
+(SMALParamGroup + torch.optim.Adam, trainer.py:111-153,194) incl. the frozen log_beta_scales.
 
 v0.2.5 definitions restated here (N meshes in the batch, all reductions at their defaults):
   chamfer_distance(x, y)        cham_x[n] = mean_i min_j |x_ni - y_nj|^2, cham_y likewise; (sum_n cham_x + cham_y) / N
