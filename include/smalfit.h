@@ -221,7 +221,7 @@ int smalfit_mesh_targets_sample(smalfit_mesh_targets* targets, void* stream, int
  *   new_src_verts = smal_3d_fitter(); loss = forward(...); loss.backward(); optimizer.step()
  * = SMAL forward on [global_rot | joint_rot], target points sampled (or taken from `points`), the four-term objective,
  * its gradient back through the SMAL model, torch.optim.Adam on every parameter whose learning rate is > 0 (the
- * parameter groups of trainer.py:113-119 with their custom learning rates) -- about 20 kernel launches, no host
+ * parameter groups of trainer.py:113-119 with their custom learning rates) -- 14 kernel launches, no host
  * synchronisation.  All pointers are device pointers unless noted.  log_beta_scales is read, never trained
  * (requires_grad=False in the reference, trainer.py:64-65). */
 typedef struct smalfit_fit3d_args {

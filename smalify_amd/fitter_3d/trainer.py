@@ -6,7 +6,7 @@ weights and their defaults (trainer.py:31), the .npz written by Stage.save_npz (
 
 What is different underneath: one Stage.step is ONE C-ABI call on the current HIP stream (smalfit_fit3d_step: SMAL
 forward, target-point sampling, all four loss terms, the gradient back through the SMAL model, Adam on the scheme's
-parameters -- about 20 kernel launches) with no autograd graph and no host synchronisation; the loss history stays on
+parameters -- 14 kernel launches) with no autograd graph and no host synchronisation; the loss history stays on
 the device until it is plotted or printed.  Stage.evaluate / Stage.step_unfused compose the same iteration from the
 component entry points (smalfit_lbs_forward, smalfit_mesh_targets_sample, smalfit_mesh_objective_eval,
 smalfit_lbs_backward, smalfit_adam_step) and expose the gradients.  The target points are drawn by a counter-based
