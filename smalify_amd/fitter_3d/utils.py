@@ -63,9 +63,18 @@ class TargetMeshes:
     (the role pytorch3d.structures.Meshes plays in fitter_3d/utils.py:253 and trainer.py:209)."""
 
     def __init__(self, verts_list, faces_list):
-        self._dev = eng.MeshTargets(verts_list, faces_list)
-        self.verts = self._dev.verts_list
-        self.faces = self._dev.faces_list
+        if len(verts_list) == 0 or len(verts_list) != len(faces_list):
+            raise ValueError("need one (verts, faces) pair per target mesh")
+        self.verts = [np.ascontiguousarray(np.asarray(v), np.float32).reshape(-1, 3) for v in verts_list]
+        self.faces = [np.ascontiguousarray(np.asarray(f), np.int32).reshape(-1, 3) for f in faces_list]
+        self._device_targets = None
+
+    @property
+    def _dev(self):
+        """the device-resident copy + sampler, uploaded on first use (loading and plotting need no GPU)"""
+        if self._device_targets is None:
+            self._device_targets = eng.MeshTargets(self.verts, self.faces)
+        return self._device_targets
 
     def __len__(self):
         return len(self.verts)

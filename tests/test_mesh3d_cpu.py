@@ -387,3 +387,35 @@ def test_stage_optimiser_semantics_match_reference_golden(scheme, lr, custom):
             assert mc.rel(got, want) < (2e-3 if k == "deform_verts" else 2e-4), (k, mc.rel(got, want))
         else:
             assert np.array_equal(got.astype(np.float32), z["p_" + k]) and np.array_equal(want, z["p_" + k]), k
+
+
+def test_load_meshes_normalises_like_the_reference(tmp_path):
+    """fitter_3d/utils.py:204-255: every .obj of the directory, names without the extension, vertices centred on their
+    mean and scaled by the largest absolute coordinate; frame_step / n_meshes; no GPU needed until points are sampled"""
+    from smalify_amd.fitter_3d import utils as u
+    rs = np.random.RandomState(4)
+    want = {}
+    for name in ("b_frame", "a_frame", "c_frame"):
+        v = (CUBE_V * rs.uniform(0.5, 3.0, size=3) + rs.uniform(-2, 2, size=3)).astype(np.float64)
+        with open(tmp_path / (name + ".obj"), "w") as fh:
+            fh.write("".join("v %.6f %.6f %.6f\n" % tuple(p) for p in v))
+            fh.write("".join("f %d %d %d\n" % tuple(f + 1) for f in CUBE_F))
+        c = v - v.mean(0)
+        want[name] = c / np.abs(c).max()
+    (tmp_path / "notes.txt").write_text("not a mesh")
+    names, meshes = u.load_meshes(str(tmp_path), sorting=sorted)
+    assert names == ["a_frame", "b_frame", "c_frame"] and len(meshes) == 3
+    for n, name in enumerate(names):
+        v, f = meshes[n]
+        assert np.abs(v - want[name]).max() < 1e-5 and np.array_equal(f, CUBE_F)
+        assert abs(np.abs(v).max() - 1.0) < 1e-6
+    names2, meshes2 = u.load_meshes(str(tmp_path), sorting=sorted, frame_step=2)
+    assert names2 == ["a_frame", "c_frame"]
+    names3, _ = u.load_meshes(str(tmp_path), sorting=sorted, n_meshes=1)
+    assert names3 == ["a_frame"]
+    with pytest.raises(FileNotFoundError):
+        u.load_meshes(str(tmp_path / "meshes_missing") if (tmp_path / "meshes_missing").mkdir() is None else "")
+    if not torch.cuda.is_available():
+        from smalify_amd import engine as eng
+        with pytest.raises(eng.SmalfitError):
+            meshes.sample(10, 0, 0)                                  # no CPU fallback for the sampler
