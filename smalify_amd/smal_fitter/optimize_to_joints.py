@@ -33,6 +33,9 @@ def write_png(path, image):
     """8-bit RGB PNG with nothing but zlib (replaces imageio.imsave, optimize_to_joints.py:45)"""
     import struct
     import zlib
+    image = np.asarray(image)
+    if np.issubdtype(image.dtype, np.floating):          # float images are taken as [0, 1]
+        image = np.clip(image, 0.0, 1.0) * 255.0 + 0.5
     img = np.ascontiguousarray(image, dtype=np.uint8)
     h, w, c = img.shape
     assert c == 3

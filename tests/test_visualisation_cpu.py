@@ -80,3 +80,26 @@ def test_png_and_ply_writers_round_trip(tmp_path):
     assert np.array_equal(np.frombuffer(body[:60], "<f4").reshape(5, 3), verts)
     rec = np.frombuffer(body[60:], dtype=[("n", "u1"), ("i", "<i4", (3,))])
     assert (rec["n"] == 3).all() and np.array_equal(rec["i"], faces)
+
+
+def test_generate_video_exporter_writes_numbered_frames(tmp_path):
+    """reference generate_video.py:24-32: one flat directory, `NNNN.png` + `NNNN.pkl` per frame (ffmpeg's %04d pattern)"""
+    import pickle
+    from PIL import Image
+    from smalify_amd.smal_fitter.generate_video import ImageExporter
+    ex = ImageExporter(str(tmp_path / "exported" / "ckpt" / "st10_ep0"))
+    rs = np.random.RandomState(0)
+    for gid in (0, 7):
+        collage = rs.rand(32, 160, 3).astype(np.float32)          # float in [0, 1]; uint8 collages pass through unchanged
+        params = {"global_rotation": rs.randn(3).astype(np.float32), "betas": rs.randn(20).astype(np.float32)}
+        ex.export(collage, gid % 4, gid, params, None, None)
+        stem = tmp_path / "exported" / "ckpt" / "st10_ep0" / ("%04d" % gid)
+        img = np.asarray(Image.open(str(stem) + ".png"))
+        assert img.shape == (32, 160, 3)
+        assert np.abs(img.astype(np.float32) / 255.0 - collage).max() <= 0.5 / 255.0 + 1e-6
+        with open(str(stem) + ".pkl", "rb") as fh:
+            back = pickle.load(fh)
+        assert np.array_equal(back["betas"], params["betas"])
+    u8 = (rs.rand(8, 8, 3) * 255).astype(np.uint8)
+    ex.export(u8, 0, 9, {}, None, None)
+    assert np.array_equal(np.asarray(Image.open(str(tmp_path / "exported" / "ckpt" / "st10_ep0" / "0009.png"))), u8)
