@@ -5,7 +5,9 @@ Loads the dataset named by config.SEQUENCE_OR_IMAGE_NAME, builds a SMALFitter, r
 and writes one five-panel collage `NNNN.png` plus the frame's parameter dict `NNNN.pkl` per frame to
 `exported/<CHECKPOINT_NAME>/<EPOCH_NAME>/` (reference generate_video.py:24-72).  Frames are numbered consecutively so
 that `ffmpeg -framerate 50 -i %04d.png -pix_fmt yuv420p out.gif` works as the reference's header comment suggests.
-No cv2 / imageio / PyTorch3D: the collage is drawn by SMALFitter.generate_visualization (HIP colour render + numpy)."""
+As in the reference, load_checkpoint looks for `<frame index:04>/<EPOCH_NAME>.pkl` while the fit exporter names its
+directories after the image stems (optimize_to_joints.py:37): the two agree only for frames named 0000.png, 0001.png …
+(BADJA crops are).  No cv2 / imageio / PyTorch3D: the collage is drawn by SMALFitter.generate_visualization (HIP colour render + numpy)."""
 from __future__ import annotations
 
 import os
