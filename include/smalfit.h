@@ -104,6 +104,13 @@ int smalfit_lbs_backward(smalfit_engine* engine, void* stream, int M, int nb, co
 int smalfit_rodrigues(void* stream, int count, const float* theta, float* R);
 int smalfit_rodrigues_backward(void* stream, int count, const float* theta, const float* dR, float* dtheta);
 
+/* replaces: batch_global_rigid_transformation(Rs, Js, parent, betas_logscale=...)   reference smal_model/batch_lbs.py:75-170
+ * Rs (count,35,3,3)  Js (count,35,3)  parents: host int[35] with parents[i] < i (parents[0] ignored)
+ * logscale (count,6) or NULL -> new_J (count,35,3), A (count,35,4,4).  Forward only: inside the fitting path the chain
+ * and its adjoint are part of smalfit_lbs_forward / _backward and smalfit_fit_eval. */
+int smalfit_global_rigid_transformation(void* stream, int count, const float* Rs, const float* Js,
+                                        const int* parents /*host*/, const float* logscale, float* new_J, float* A);
+
 /* ---- Renderer.forward ---------------------------------------------------------------------------
  * replaces: Renderer.forward(vertices, points, faces)        reference smal_fitter/p3d_renderer.py:61-74
  * verts (M,V,3) world space -> sil (M,S,S) soft silhouette (sigma 1e-4, blur log(9999)*1e-4, K=100)

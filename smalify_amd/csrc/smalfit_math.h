@@ -99,6 +99,67 @@ SMALFIT_HD void mat3T_vec(const float A[9], const float v[3], float o[3]) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// kinematic chain of one frame, free-standing (batch_global_rigid_transformation, batch_lbs.py:75-170)
+// ------------------------------------------------------------------------------------------------
+// limb log-scale driving (joint j, axis a), or -1 (batch_lbs.py:107-121: legs 7..14, 17..24; tail 25..31; ears 33, 34)
+SMALFIT_HD int limb_scale_index(int j, int a) {
+  if (j >= 7 && j < 25 && j != 15 && j != 16) return a == 2 ? 0 : 1;
+  if (j >= 25 && j < 32) return a == 0 ? 2 : 3;
+  if (j == 33 || j == 34) return a == 1 ? 4 : (a == 2 ? 5 : -1);
+  return -1;
+}
+
+// Rs [35][9], Js [35][3], parents [35] (parents[i] < i), logscale [6] or null -> newJ [35][3], A [35][16] (4x4 row-major).
+// G_0 = [R_0 | J_0] (the root is not scaled), G_i = G_p [S_p^-1 R_i S_i | J_i - J_p]; newJ_i = G_i[:3,3];
+// A_i = G_i with its last column replaced by t - G_i[:3,:3] J_i.  The chain is held in A itself (rows 0..2).
+SMALFIT_HD void global_rigid_frame(const float* Rs, const float* Js, const int* parents, const float* logscale,
+                                   float* newJ, float* A) {
+  float es[6], ies[6];
+  for (int k = 0; k < 6; ++k) {
+    es[k] = logscale != nullptr ? expf(logscale[k]) : 1.0f;
+    ies[k] = 1.0f / es[k];
+  }
+  for (int i = 0; i < kJoints; ++i) {
+    float* G = A + 16 * i;
+    if (i == 0) {
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) G[r * 4 + c] = Rs[r * 3 + c];
+        G[r * 4 + 3] = Js[r];
+      }
+    } else {
+      const int p = parents[i];
+      const float* Gp = A + 16 * p;
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) {
+          const int si = limb_scale_index(i, c);
+          const float sc = si >= 0 ? es[si] : 1.0f;
+          float acc = 0.f;
+          for (int q = 0; q < 3; ++q) {
+            const int sp = limb_scale_index(p, q);
+            const float isc = sp >= 0 ? ies[sp] : 1.0f;
+            acc = fmaf(Gp[r * 4 + q], Rs[9 * i + q * 3 + c] * sc * isc, acc);
+          }
+          G[r * 4 + c] = acc;
+        }
+        float acc = Gp[r * 4 + 3];
+        for (int q = 0; q < 3; ++q) acc = fmaf(Gp[r * 4 + q], Js[3 * i + q] - Js[3 * p + q], acc);
+        G[r * 4 + 3] = acc;
+      }
+    }
+    G[12] = 0.f; G[13] = 0.f; G[14] = 0.f; G[15] = 1.0f;
+  }
+  for (int i = 0; i < kJoints; ++i) {
+    float* G = A + 16 * i;
+    for (int r = 0; r < 3; ++r) {
+      newJ[3 * i + r] = G[r * 4 + 3];
+      float val = G[r * 4 + 3];
+      for (int q = 0; q < 3; ++q) val = fmaf(-G[r * 4 + q], Js[3 * i + q], val);
+      G[r * 4 + 3] = val;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // camera: world -> (x_ndc, y_ndc, z_view) and its adjoint
 // ------------------------------------------------------------------------------------------------
 SMALFIT_HD void world_to_ndc(float x, float y, float z, float& xn, float& yn, float& zv) {

@@ -280,6 +280,25 @@ def rodrigues_backward(theta, dR):
     return dth
 
 
+def global_rigid_transformation(Rs, Js, parents, logscale=None):
+    """Rs (N,35,3,3), Js (N,35,3), parents (35,) host ints, logscale (N,6) or None -> new_J (N,35,3), A (N,35,4,4)
+    (reference batch_lbs.py:75-170; forward only)"""
+    lib = _lib.load()
+    N = int(Rs.shape[0])
+    if tuple(Rs.shape) != (N, 35, 3, 3) or tuple(Js.shape) != (N, 35, 3):
+        raise SmalfitError("Rs must be (N,35,3,3) and Js (N,35,3)")
+    if logscale is not None and tuple(logscale.shape) != (N, 6):
+        raise SmalfitError("betas_logscale must be (N,6)")
+    par = _host(parents, np.int32).reshape(-1)
+    if par.shape[0] != 35:
+        raise SmalfitError("parents must hold 35 entries")
+    new_J = torch.empty(N, 35, 3, device=Rs.device)
+    A = torch.empty(N, 35, 4, 4, device=Rs.device)
+    check(lib.smalfit_global_rigid_transformation(_stream(), N, _ptr(Rs), _ptr(Js), par.ctypes.data, _ptr(logscale),
+                                                  _ptr(new_J), _ptr(A)), "smalfit_global_rigid_transformation")
+    return new_J, A
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, t, beta1=0.5, beta2=0.999, eps=1e-8):
     """In-place torch.optim.Adam step on a flat float32 device tensor (reference optimize_to_joints.py:96,137)."""
     lib = _lib.load()

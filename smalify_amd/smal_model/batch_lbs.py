@@ -1,10 +1,11 @@
 """Drop-in for reference smal_model/batch_lbs.py (the functions the fitting path uses).
 
 batch_rodrigues runs the HIP kernel (smalfit_rodrigues) with an analytic adjoint.
-batch_global_rigid_transformation as a free-standing differentiable function is not exposed yet: the
-kinematic chain lives inside SMAL.__call__ (pose_kernel / chain_bwd_kernel); calling it raises."""
+batch_global_rigid_transformation runs smalfit_global_rigid_transformation (forward only: inside the fitting path the
+chain and its adjoint are fused into SMAL.__call__, lbs_head_kernel / chain_bwd_kernel)."""
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from .. import engine as eng
@@ -28,7 +29,23 @@ def batch_rodrigues(theta, opts=None):
     return _Rodrigues.apply(theta)
 
 
+class _GlobalRigid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Rs, Js, logscale, parent):
+        ls = None if logscale is None else logscale.contiguous().float()
+        new_J, A = eng.global_rigid_transformation(Rs.contiguous().float(), Js.contiguous().float(), parent, ls)
+        return new_J, A
+
+    @staticmethod
+    def backward(ctx, d_new_J, d_A):
+        raise NotImplementedError(
+            "batch_global_rigid_transformation is forward-only here; gradients of the kinematic chain flow through "
+            "SMAL.__call__ (smalfit_lbs_backward), which is how the reference's fitters reach it")
+
+
 def batch_global_rigid_transformation(Rs, Js, parent, rotate_base=False, betas_logscale=None, opts=None):
-    raise NotImplementedError(
-        "smalify_amd fuses the kinematic chain into SMAL.__call__ (HIP pose_kernel); the free-standing "
-        "batch_global_rigid_transformation of reference batch_lbs.py:75-170 is not exposed")
+    """Rs (N,35,3,3), Js (N,35,3), parent (35,) -> new_J (N,35,3), A (N,35,4,4)   (reference batch_lbs.py:75-170).
+    rotate_base=True fails in the reference too (`torch.repeat` does not exist, batch_lbs.py:93) and is rejected."""
+    if rotate_base:
+        raise NotImplementedError("rotate_base=True is broken in the reference (batch_lbs.py:91-94) and not supported")
+    return _GlobalRigid.apply(Rs, Js, betas_logscale, np.asarray(parent))

@@ -76,6 +76,13 @@ void hm_raster(const float* v, int V, const int* faces, int F, int S, const floa
   }
 }
 
+// global_rigid_kernel on the host: one call of global_rigid_frame per frame
+void hm_global_rigid(int n, const float* Rs, const float* Js, const int* parents, const float* logscale, float* newJ, float* A) {
+  for (int i = 0; i < n; ++i)
+    global_rigid_frame(Rs + (size_t)i * 315, Js + (size_t)i * 105, parents, logscale ? logscale + (size_t)i * 6 : nullptr,
+                       newJ + (size_t)i * 105, A + (size_t)i * 560);
+}
+
 void hm_camera(int n, const float* p, const float* g2, float* ndc, float* g3) {
   for (int i = 0; i < n; ++i) {
     world_to_ndc(p[3 * i], p[3 * i + 1], p[3 * i + 2], ndc[3 * i], ndc[3 * i + 1], ndc[3 * i + 2]);

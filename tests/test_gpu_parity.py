@@ -108,3 +108,22 @@ def test_fit_loop_with_silhouette_follows_the_oracle(M, S, window, iters):
     for k, v in m.items():
         if k.endswith("_rel") and k != "traj_loss_rel_max":
             assert v < 1e-4, (k, v, m)
+
+
+@pytest.mark.parametrize("scaled", [False, True])
+def test_global_rigid_transformation_against_reference_golden(golden, scaled):
+    """the free-standing batch_global_rigid_transformation drop-in (smalfit_global_rigid_transformation) against the
+    reference's own outputs (tests/golden, G2), with and without limb scales"""
+    import numpy as np
+    from smalify_amd.smal_model.batch_lbs import batch_global_rigid_transformation, batch_rodrigues
+    theta = torch.from_numpy(golden["g2_theta"]).cuda()
+    Rs = batch_rodrigues(theta).reshape(3, 35, 3, 3)
+    Js = torch.from_numpy(golden["g2_Js"]).cuda()
+    ls = torch.from_numpy(golden["g2_ls"]).cuda() if scaled else None
+    new_J, A = batch_global_rigid_transformation(Rs, Js, golden["parents"], betas_logscale=ls)
+    tag = "scale" if scaled else "noscale"
+    assert pc.rel(new_J.cpu().numpy(), golden["g2_newJ_" + tag]) < 2e-6
+    assert pc.rel(A.cpu().numpy(), golden["g2_A_" + tag]) < 2e-6
+    assert (A.cpu().numpy()[:, :, 3, :] == np.array([0, 0, 0, 1.0], np.float32)).all()
+    with pytest.raises(NotImplementedError):
+        batch_global_rigid_transformation(Rs, Js, golden["parents"], rotate_base=True)

@@ -100,3 +100,24 @@ def test_raster_math_host(shim, synth_model, S, z):
     go = v.grad[0].numpy()
     err = np.linalg.norm(gw - go) / np.linalg.norm(go)
     assert err < 2e-3, err
+
+
+@pytest.mark.parametrize("scaled", [False, True])
+def test_global_rigid_transformation_host_against_reference_golden(shim, golden, scaled):
+    """the free-standing kinematic chain (smalfit_global_rigid_transformation's per-frame function, compiled for the host)
+    against outputs of the reference's batch_global_rigid_transformation (tests/golden, G2), with and without limb scales"""
+    th = golden["g2_theta"]
+    Rs = np.zeros((len(th), 9), np.float32)
+    dummy = np.zeros((len(th), 3), np.float32)
+    shim.hm_rodrigues(len(th), _p(np.ascontiguousarray(th)), _p(np.zeros((len(th), 9), np.float32)), _p(Rs), _p(dummy))
+    n = 3
+    Js = np.ascontiguousarray(golden["g2_Js"], np.float32)
+    ls = np.ascontiguousarray(golden["g2_ls"], np.float32) if scaled else None
+    parents = np.ascontiguousarray(golden["parents"], np.int32)
+    newJ, A = np.zeros((n, 35, 3), np.float32), np.zeros((n, 35, 4, 4), np.float32)
+    shim.hm_global_rigid(n, _p(Rs), _p(Js), _p(parents), None if ls is None else _p(ls), _p(newJ), _p(A))
+    tag = "scale" if scaled else "noscale"
+    want_J, want_A = golden["g2_newJ_" + tag], golden["g2_A_" + tag]
+    assert np.linalg.norm(newJ - want_J) / np.linalg.norm(want_J) < 2e-6
+    assert np.linalg.norm(A - want_A) / np.linalg.norm(want_A) < 2e-6
+    assert (A[:, :, 3, :] == np.array([0, 0, 0, 1.0], np.float32)).all()
