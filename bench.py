@@ -1,27 +1,39 @@
 #!/usr/bin/env python3
 """Benchmark of the SMAL per-frame fitting hot path on MI355X.
 
-metric  : fitter iterations/sec  (BASELINE.json) — one iteration = one epoch of the reference loop
+metric  : fitter iterations/sec  (BASELINE.json) -- one iteration = one epoch of the reference loop
           (smal_fitter/optimize_to_joints.py:113-137): LBS + projection + soft-silhouette render + all
           losses + temporal term + full gradient + Adam step over the whole batch.
 workload: synthetic BADJA-shape sequence, 64 frames, 256x256, WINDOW_SIZE 8, shape family 1 with the
           unity-style shape prior, synthetic SMAL-topology model (V=3889, F=7774).  The K timed steps run
           the reference's 4-stage schedule (150:400:600:800 iterations, config.py:63-72) scaled to K
-          iterations, each stage with its own weights / learning rate / fresh Adam state.
-          With --steps 1950 the timed region is exactly one complete fit.
+          iterations, each stage with its own weights / learning rate / fresh Adam state, one library
+          call (smalfit_fit_run) per stage.  With --steps 1950 the timed region is exactly one complete fit.
 
-One process per GPU (python -m torch.distributed.run ... bench.py --gpus N): frames are sharded
-contiguously across ranks (strong scaling), see smalify_amd/distributed.py.
+timing  : W untimed warm-up steps, then EXACTLY K steps between (barrier +) torch.cuda.synchronize() on both
+          sides, nothing synchronising in between (per-stage times come from HIP events on the launch stream).
+          The warm-up is at least INTERNAL_WARMUP iterations whatever --warmup says (clocks, code objects, allocator)
+          and ends with ONE silhouette evaluation of the timed fit's initial state (no parameter update), which
+          hands the rasteriser's per-pixel depth-bound cache the pose the timed region starts from: the reference
+          renders the silhouette in every stage-0 iteration too (smal_fitter.py:134), and a K-step window of a
+          1950-step fit would otherwise charge the one-off cold selection of the whole fit to 1/K of the steps.
+          The JSON reports the real number of warm-up steps.
+
+multi-GPU: `python bench.py --gpus N` launches N ranks itself (torch.distributed.run, one process per GPU, RCCL)
+          when it is not already running under a launcher; under `python -m torch.distributed.run ... bench.py
+          --gpus N` it is one of the ranks.  Frames are sharded contiguously across ranks (strong scaling: the
+          64-frame sequence is BASELINE.json's config 4), see smalify_amd/distributed.py.
 
 Prints ONE JSON line on rank 0.
 
-SMALFIT_BENCH_FORCE_DIST=1 (validation hook): initialise the process group and run the sharded step with its
-all-gather even when WORLD_SIZE is 1, so that the RCCL path can be exercised on a single-GPU box
-(python -m torch.distributed.run --nproc-per-node 1 ... bench.py).
+SMALFIT_BENCH_FORCE_DIST=1 (validation hook): run the sharded step with its all-gather even when the world is one
+rank, so that the RCCL path can be exercised on a single-GPU box.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,9 +48,9 @@ IMAGE_SIZE = 256
 WINDOW = 8
 SCHEDULE_ITERS = (150, 400, 600, 800)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-
-
+INTERNAL_WARMUP = 40           # minimum number of untimed iterations before the timed region
 PROFILE_STRIDE = 8
+PMC_SUMMARY = os.path.join("profiles", "r2_pmc_summary.json")
 
 
 def scaled_schedule(total):
@@ -77,17 +89,19 @@ def build_problem(engine, torch, scene):
 
 def cpu_baseline(md, pose_prior, shape_prior, target_joints, vis, target_sil, stage_weights, w_temp):
     """Times the oracle (CPU port of the same maths: torch float32, pair-list rasteriser, autograd backward, Adam) on a
-    bounded sample of the same workload: one stage-2-type iteration over the first `nf` of the 64 frames, where nf is
-    chosen from a 1-frame probe so that the sample costs roughly 10-15 s; extrapolated linearly to 64 frames.
-    torch intra-op threads are capped at 16 (the oracle's tensors are small; more threads only add contention)."""
+    bounded sample of the same workload: CPU_ITERS stage-2-type iterations (silhouette on) over the first `nf` of the 64
+    frames, nf chosen from a 1-frame probe so that the sample costs roughly 15 s; the per-iteration time is the mean
+    of the timed iterations (the first one, which also builds nothing reusable, is included), extrapolated linearly
+    to 64 frames.  torch intra-op threads are capped at 16 (the oracle's tensors are small; more only add contention)."""
     import torch
     from oracle import smal_oracle as so
     from smalify_amd import model_io
+    CPU_ITERS = 5
     ncores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(ncores)
     om = so.OracleModel(md, dtype=torch.float32)
 
-    def one_iteration(nf):
+    def iterations(nf, count):
         prob = so.FitProblem(om, IMAGE_SIZE, target_joints[:nf], vis[:nf], target_sil[:nf], pose_prior[0], pose_prior[1],
                              pose_prior[2], shape_prior[0], shape_prior[1], min(WINDOW, nf), True, dtype=torch.float32)
         params = dict(betas=torch.from_numpy(shape_prior[1][:20].copy()),
@@ -96,20 +110,51 @@ def cpu_baseline(md, pose_prior, shape_prior, target_joints, vis, target_sil, st
                       trans=torch.zeros(nf, 3), joint_rotations=torch.zeros(nf, 34, 3))
         opt = so.Adam(so.PARAM_ORDER, lr=5e-4)
         t0 = time.perf_counter()
-        total, sums, grads = so.loss_and_grads(prob, params, stage_weights, w_temp, so.PARAM_ORDER)
-        opt.step(params, grads)
-        dt = time.perf_counter() - t0
-        assert sums.get("sil_reproj", 0.0) > 0.0, "silhouette term missing from the CPU baseline sample"
-        return dt
+        for _ in range(count):
+            total, sums, grads = so.loss_and_grads(prob, params, stage_weights, w_temp, so.PARAM_ORDER)
+            opt.step(params, grads)
+            assert sums.get("sil_reproj", 0.0) > 0.0, "silhouette term missing from the CPU baseline sample"
+        return (time.perf_counter() - t0) / count
 
-    t1 = one_iteration(1)
-    nf = int(max(1, min(NUM_FRAMES, 12.0 / max(t1, 1e-3))))
-    dt = one_iteration(nf) if nf > 1 else t1
-    per_iter_64 = dt * (NUM_FRAMES / nf)
+    t1 = iterations(1, 1)
+    nf = int(max(1, min(NUM_FRAMES, 15.0 / (CPU_ITERS * max(t1, 1e-3)))))
+    per_iter = iterations(nf, CPU_ITERS)
+    per_iter_64 = per_iter * (NUM_FRAMES / nf)
     return {"value": 1.0 / per_iter_64, "unit": "iterations/s", "cores": ncores, "kind": "port",
-            "sample": "oracle (torch CPU float32 restatement, pair-list rasteriser) on %d of 64 frames, 1 stage-2-type "
-                      "iteration incl. backward + Adam: %.2f s (1-frame probe %.2f s); extrapolated x%.2f"
-                      % (nf, dt, t1, NUM_FRAMES / nf)}
+            "sample": "oracle (torch CPU float32 restatement, pair-list rasteriser) on %d of 64 frames, %d stage-2-type "
+                      "iterations incl. backward + Adam: %.2f s per iteration (1-frame probe %.2f s); extrapolated x%.2f"
+                      % (nf, CPU_ITERS, per_iter, t1, NUM_FRAMES / nf)}
+
+
+def final_loss_parity():
+    """The metric's second half ('final keypoint/sil loss vs ref') on a side problem small enough for the CPU oracle:
+    the whole 4-stage schedule (scaled) on 2 frames at 64x64, HIP engine vs the oracle's loop from the same start.
+    The same comparison at 4 frames / scale 0.1 is asserted by tests/test_gpu_parity.py::test_full_schedule."""
+    from tests import parity_cases as pc
+    m = pc.case_full_schedule(M=2, S=64, window=2, iters_scale=0.03)
+    keep = {"frames": 2, "image_size": 64, "schedule": m["schedule"], "final_total_rel": m["final_total_rel"]}
+    for k in ("joint", "sil_reproj"):
+        keep["final_%s_hip" % k] = m["final_%s_hip" % k]
+        keep["final_%s_oracle" % k] = m["final_%s_oracle" % k]
+        keep["final_%s_rel" % k] = m["final_%s_rel" % k]
+    keep["param_rel_l2"] = {k[6:-7]: m[k] for k in m if k.startswith("param_")}
+    return keep
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """not under a launcher and more than one GPU asked for: start one rank per GPU and relay rank 0's JSON line"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -120,6 +165,8 @@ def main():
     ap.add_argument("--scene", default="survey", choices=["survey", "crop"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     # stdout must carry exactly one JSON line: libraries write there too (RCCL prints a version banner when the
     # communicator is created), so file descriptor 1 points at stderr for the whole run and the line goes to the saved one
@@ -134,20 +181,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (smalify_amd has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    if torch.cuda.device_count() < world // max(1, int(os.environ.get("SMALFIT_BENCH_RANKS_PER_GPU", "1"))):
+        raise SystemExit("bench.py: %d rank(s) but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     force_dist = os.environ.get("SMALFIT_BENCH_FORCE_DIST") == "1"
     use_dist = world > 1 or force_dist
     if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        assert dist.get_world_size() == world
 
     md = synthetic.synthetic_model(seed=0, shape_family_id=1)
     dm = eng.DeviceModel(md)
     full_engine = eng.Engine(dm, NUM_FRAMES, IMAGE_SIZE)
     pose_prior = synthetic.synthetic_pose_prior()
     gt, tj, vis, tsil, shape_prior = build_problem(full_engine, torch, args.scene)
-    lo, hi = distributed.shard_range(NUM_FRAMES, rank, world)
+    lo, hi = distributed.shard_range(NUM_FRAMES, rank, world, WINDOW)
     if world > 1:
         del full_engine
         torch.cuda.empty_cache()
@@ -164,84 +216,108 @@ def main():
 
     W = np.array(config.OPT_WEIGHTS).T
 
-    def run(fitter, iters_per_stage, stage_seconds=None):
+    def run(fitter, iters_per_stage, events=None):
+        """the stage loop of optimize_to_joints.py:90-137; unsharded: ONE library call per stage"""
         for stage_id, its in enumerate(iters_per_stage):
+            if events is not None:
+                events[stage_id].record()
             fitter.begin_stage(stage_id)
-            t_stage = time.perf_counter()
-            for _ in range(its):
-                fitter.step(W[stage_id][:6], float(W[stage_id][6]), float(W[stage_id][8]), stage_id)
-            if stage_seconds is not None:      # per-stage rates: one device sync per stage, 4 in the run
-                torch.cuda.synchronize()
-                stage_seconds.append(time.perf_counter() - t_stage)
+            if its == 0:
+                continue
+            w = W[stage_id]
+            if use_dist:                      # the collective sits between the two halves of every iteration
+                for _ in range(its):
+                    fitter.step(w[:6], float(w[6]), float(w[8]), stage_id)
+            else:
+                fitter.run_iterations(w[:6], float(w[6]), float(w[8]), stage_id, its)
+        if events is not None:
+            events[len(iters_per_stage)].record()
 
     def sync():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warmup (untimed): W iterations with the same stage mix ---------------------------------------
-    run(new_fitter(), scaled_schedule(max(args.warmup, 4)))
+    # ---- warm-up (untimed) --------------------------------------------------------------------------------
+    n_warm = max(args.warmup, INTERNAL_WARMUP)
+    run(new_fitter(), scaled_schedule(n_warm))
     fitter = new_fitter()
-    sched = scaled_schedule(args.steps)
     base = fitter.fitter if use_dist else fitter
+    base.evaluate(W[1][:6], float(W[1][6]), 1, want=())      # silhouette of the initial state: primes the depth-bound cache
+    n_warm += 1
+    sched = scaled_schedule(args.steps)
     # HIP events on the launch stream inside the timed region, on every 8th iteration (an event record costs ~5 us
-    # of stream time; all sections of every iteration would slow the measured loop by ~8 %)
+    # of stream time; all sections of every iteration would slow the measured loop by several percent)
     base.e.profile_begin(args.steps, PROFILE_STRIDE)
+    stage_events = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     sync()
     t0 = time.perf_counter()
-    stage_seconds = []
-    run(fitter, sched, stage_seconds)
+    run(fitter, sched, stage_events)
+    t_issued = time.perf_counter() - t0
     sync()
     elapsed = time.perf_counter() - t0
     if use_dist:
         tmax = torch.tensor([elapsed], device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    stage_seconds = [stage_events[i].elapsed_time(stage_events[i + 1]) * 1e-3 for i in range(4)]
     sections = base.e.profile_end()
     status = base.e.status()
-    final_losses = base.losses.cpu().numpy().tolist()
+    final_losses = (fitter.global_losses() if use_dist else base.losses).cpu().numpy().tolist()
 
     if rank == 0:
         V, F, S = md.num_verts, md.num_faces, IMAGE_SIZE
         nloc = hi - lo
         sec_ms = {k: (v[0] / v[1] if v[1] else None) for k, v in sections.items()}
-        # dominant kernel: whichever rasteriser kernel has the largest average launch time in this run.  Algorithmic
-        # bytes per launch: the forward rasteriser must read the projected vertices (12 V per frame),
-        # the faces (12 F) and the target silhouette (4 S^2 per frame) and produce the per-pixel adjoint seed.
-        algo_bytes = nloc * (4 * S * S + 12 * V) + 12 * F
-        cand = {k: sec_ms[k] for k in ("raster_sweep", "raster_select", "raster_resolve", "raster_bwd") if sec_ms.get(k)}
+        # dominant kernel: whichever rasteriser kernel has the largest average launch time in this run (HIP events
+        # around that kernel alone).  Algorithmic bytes per launch (DESIGN.md section 5) of the two face sweeps: the
+        # frame's projected vertices (12 V per frame) and the faces (12 F) in, the per-pixel sums / per-face adjoints
+        # are intermediates.  The target silhouette belongs to the resolve kernel, which reads it.
+        algo = {"raster_sweep": nloc * 12 * V + 12 * F, "raster_bwd": nloc * 12 * V + 12 * F + nloc * 24 * F,
+                "raster_select": nloc * 12 * V + 12 * F, "raster_resolve": nloc * 4 * S * S}
+        kernel_of = {"raster_sweep": "raster_sweep_kernel", "raster_select": "raster_select_kernel",
+                     "raster_resolve": "raster_resolve_kernel", "raster_bwd": "raster_bwd_kernel"}
+        cand = {k: sec_ms[k] for k in kernel_of if sec_ms.get(k)}
         dom_name = max(cand, key=cand.get) if cand else None
         dom = cand.get(dom_name) if dom_name else None
+        algo_bytes = algo.get(dom_name)
         achieved = algo_bytes / (dom * 1e-3) / 1e9 if dom else None
-        # HBM traffic per launch of that kernel from the rocprofv3 PMC passes committed under profiles/
-        # (tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate runs; KiB, raw -- on gfx950 FETCH_SIZE
-        # under-reports wide coalesced reads by 2x, MI355X_MICROARCH.md, so this is a lower bound)
-        traffic = None
+        # HBM traffic per launch of that kernel: rocprofv3 PMC passes of this command (tools/pmc_sq.py: FETCH_SIZE and
+        # WRITE_SIZE in separate runs), committed under profiles/ -- counters cannot be read from inside the run
+        traffic, traffic_source = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")))
-            kname = "smalfit::" + {"raster_sweep": "raster_sweep_kernel", "raster_select": "raster_select_kernel",
-                                   "raster_resolve": "raster_resolve_kernel", "raster_bwd": "raster_bwd_kernel"}[dom_name]
-            traffic = 1024.0 * (pmc["fetch"].get(kname, {}).get("avg_per_row", 0.0) + pmc["write"].get(kname, {}).get("avg_per_row", 0.0))
+            pmc = json.load(open(os.path.join(ROOT, PMC_SUMMARY)))
+            row = pmc["smalfit::" + kernel_of[dom_name]]
+            traffic = 1024.0 * (2.0 * row["FETCH_SIZE"] + row["WRITE_SIZE"])   # KiB; FETCH_SIZE x2: gfx950 correction
+            traffic_source = PMC_SUMMARY + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, separate passes; " \
+                                           "FETCH_SIZE doubled per MI355X_MICROARCH.md)"
         except Exception:
-            traffic = None
+            pass
+        ms_per_step = 1e3 * elapsed / args.steps
+        iter_bytes = 2 * 16442644 + NUM_FRAMES * (4 * S * S + 3324)            # SURVEY.md section 8d: 49.88 MB / iteration
         out = {
             "metric": "fitter iterations/sec", "value": args.steps / elapsed, "unit": "iterations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "n_gpus": world, "steps": args.steps, "warmup": n_warm, "warmup_requested": args.warmup,
+            "ms_per_step": ms_per_step, "host_issue_ms_per_step": 1e3 * t_issued / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "synthetic BADJA-shape sequence: %d frames, %dx%d, WINDOW_SIZE %d, shape family 1, "
                                    "reference 4-stage schedule scaled to %d iterations %s, scene=%s"
                                    % (NUM_FRAMES, S, S, WINDOW, args.steps, sched, args.scene),
                        "frames": NUM_FRAMES, "image_size": S, "window": WINDOW, "parallelism": "frames/%d" % world},
-            "per_stage_iterations_per_s": {"stage%d" % i: (sched[i] / stage_seconds[i] if stage_seconds[i] > 0 else None)
+            "per_stage_iterations_per_s": {"stage%d" % i: (sched[i] / stage_seconds[i] if stage_seconds[i] > 0 and sched[i] else None)
                                            for i in range(len(sched))},
-            "roofline": {"bound": "hbm", "kernel": {"raster_sweep": "raster_sweep_kernel", "raster_select": "raster_select_kernel", "raster_resolve": "raster_resolve_kernel", "raster_bwd": "raster_bwd_kernel"}.get(dom_name), "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": kernel_of.get(dom_name), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": dom},
+                         "traffic_source": traffic_source, "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": dom,
+                         # whole iteration, whole job: SURVEY.md section 8d's byte formula over the measured step, against N x peak
+                         "iteration": {"algorithmic_bytes": iter_bytes, "achieved": iter_bytes / (ms_per_step * 1e-3) / 1e9,
+                                       "frac": iter_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)}},
             "section_ms": sec_ms, "final_losses": dict(zip(eng.LOSS_NAMES, final_losses)), "status_bits": status,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(md, pose_prior, shape_prior, tj.cpu().numpy(), vis.cpu().numpy(),
                                                tsil.cpu().numpy(), W[2][:6], float(W[2][6]))
+            out["final_loss_vs_ref"] = final_loss_parity()
         line = json.dumps(out)
     if use_dist:
         dist.destroy_process_group()

@@ -68,13 +68,14 @@ int smalfit_engine_reset_raster_cache(smalfit_engine* engine, void* stream);
  * ~5 us of stream time on MI355X, so timing every evaluation would slow the loop it measures by several percent);
  * profile_end synchronises `stream`, and returns the summed milliseconds and the number of timed evaluations per
  * section. */
-#define SMALFIT_NUM_SECTIONS 6
+#define SMALFIT_NUM_SECTIONS 7
 #define SMALFIT_SEC_LBS_FWD 0        /* lbs_head (pose, shape blend, shape prior) + skin + joints kernels */
-#define SMALFIT_SEC_RASTER_SWEEP 1   /* face_bbox_kernel + raster_sweep_kernel                     */
+#define SMALFIT_SEC_RASTER_SWEEP 1   /* raster_sweep_kernel alone                                  */
 #define SMALFIT_SEC_RASTER_SELECT 2  /* raster_select_kernel alone (K-nearest selection)          */
 #define SMALFIT_SEC_RASTER_BWD 3     /* raster_bwd_kernel alone                                   */
 #define SMALFIT_SEC_LBS_BWD 4        /* vertex, mid-stage (dA, pose-blend, shape-blend) and chain adjoints */
 #define SMALFIT_SEC_RASTER_RESOLVE 5 /* raster_resolve_kernel + raster_band_kernel                  */
+#define SMALFIT_SEC_RASTER_BBOX 6    /* face_bbox_kernel (per-face pixel boxes and records)        */
 int smalfit_engine_profile_begin(smalfit_engine* engine, int max_evals, int stride);
 int smalfit_engine_profile_end(smalfit_engine* engine, void* stream, float* ms_total, int* counts);
 
@@ -167,6 +168,44 @@ typedef struct smalfit_fit_args {
 } smalfit_fit_args;
 
 int smalfit_fit_eval(smalfit_engine* engine, void* stream, const smalfit_fit_args* args);
+
+/* ---- the epoch loop: loss + backward + optimizer.step(), `iterations` times in one call ---------------------------
+ * replaces: the body of the epoch loop                        reference smal_fitter/optimize_to_joints.py:113-137
+ *   optimizer.zero_grad(); acc_loss = sum over windows of model(...) + temporal; acc_loss.backward(); optimizer.step()
+ * with optimizer = torch.optim.Adam(model.parameters(), lr, betas=(0.5, 0.999)) created per stage (:96).
+ * The fit parameters, their gradient and the two Adam moments are four flat device buffers of one layout (the caller
+ * chooses it; the pointers inside smalfit_fit_args point into `param` / `grad`); the trainable tensors of the stage are
+ * up to four [begin, end) ranges of that layout and are updated by ONE kernel launch per iteration.
+ * step = optimiser steps already taken in this stage; when it is 0 the moments are taken as zero and not read, so a new
+ * stage needs no fill.  Everything is enqueued on `stream`; nothing synchronises. */
+typedef struct smalfit_adam_args {
+  float* param;        /* flat parameters                                   */
+  float* grad;         /* their gradient (written by the evaluation)        */
+  float* exp_avg;      /* Adam first moment                                 */
+  float* exp_avg_sq;   /* Adam second moment                                */
+  int num_segments;    /* 0..4 trainable ranges of the flat layout          */
+  int seg_begin[4];
+  int seg_end[4];
+  float lr, beta1, beta2, eps;
+  int step;            /* steps already taken by this stage's optimiser     */
+} smalfit_adam_args;
+int smalfit_fit_run(smalfit_engine* engine, void* stream, const smalfit_fit_args* args, const smalfit_adam_args* adam,
+                    int iterations);
+/* optimizer.step() alone on the ranges (t = adam->step + 1) */
+int smalfit_adam_segments(void* stream, const smalfit_adam_args* adam);
+
+/* ---- frame-sharded fitting (one process per GPU; no counterpart in the reference) --------------------
+ * Per iteration a rank evaluates its frames, steps its per-frame parameters, and contributes one record to an
+ * all-gather: record = [partial gradient of the shared parameters (num_shared) | masked theta(105)|trans(3) of its first
+ * frame | of its last frame] -- the partial shape gradient and the neighbours' temporal halo of the next iteration. */
+int smalfit_shard_record(void* stream, int num_shared, const float* shared_grad, int num_frames,
+                         const float* global_rotation, const float* joint_rotations, const float* trans,
+                         const float* global_mask /*(3,)*/, const float* rotation_mask /*(34,3)*/,
+                         float* record /*(num_shared + 216)*/);
+/* after the all-gather: grad[0:num_shared] = sum over ranks (in rank order: the same bits on every rank) of the gathered
+ * partial gradients, then Adam (t = adam->step + 1) on the first num_trainable of them.  gathered: (world_size, record_stride) */
+int smalfit_shard_reduce_step(void* stream, int world_size, int record_stride, const float* gathered, int num_shared,
+                              int num_trainable, const smalfit_adam_args* adam);
 
 /* ---- Prior.__call__ ---------------------------------------------------------------------------------
  * replaces: Prior.__call__(x)                                 reference smal_fitter/priors/pose_prior_35.py:112-124

@@ -43,6 +43,13 @@ class FitArgs(C.Structure):
                 ("verts_out", C.c_void_p)]
 
 
+class AdamArgs(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("num_segments", C.c_int), ("seg_begin", C.c_int * 4), ("seg_end", C.c_int * 4),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("step", C.c_int)]
+
+
 class Fit3dArgs(C.Structure):
     _fields_ = [("num_meshes", C.c_int), ("num_betas", C.c_int), ("num_points", C.c_int),
                 ("betas", C.c_void_p), ("log_beta_scales", C.c_void_p), ("global_rot", C.c_void_p),
@@ -84,6 +91,10 @@ SIGNATURES = {
     "smalfit_render_backward": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP]),
     "smalfit_project_points_backward": (_I, [_VP, _I, _I, _VP, _VP, _VP]),
     "smalfit_fit_eval": (_I, [_VP, _VP, C.POINTER(FitArgs)]),
+    "smalfit_fit_run": (_I, [_VP, _VP, C.POINTER(FitArgs), C.POINTER(AdamArgs), _I]),
+    "smalfit_adam_segments": (_I, [_VP, C.POINTER(AdamArgs)]),
+    "smalfit_shard_record": (_I, [_VP, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "smalfit_shard_reduce_step": (_I, [_VP, _I, _I, _VP, _I, _I, C.POINTER(AdamArgs)]),
     "smalfit_pose_prior": (_I, [_VP, _VP, _I, _VP, _VP]),
     "smalfit_pose_prior_backward": (_I, [_VP, _VP, _I, _VP, _VP, _VP]),
     "smalfit_temporal": (_I, [_VP, _VP, _I, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

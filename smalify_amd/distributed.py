@@ -12,6 +12,9 @@ the temporal term (smal_fitter.py:177-190) couples only adjacent frames.  Per it
      next iteration,
   4. adds the partial shape gradients in rank order (identical on every rank, deterministic) and applies Adam
      to the shared parameters, which therefore evolve identically everywhere.
+With the HIP engine steps 1-3a are two library calls (smalfit_fit_run for one iteration on the per-frame ranges,
+smalfit_shard_record), step 4 is one kernel (smalfit_shard_reduce_step): one extra launch on each side of the
+collective, no torch arithmetic on the path.
 
 One latency-bound collective of ~1 KB per iteration on xGMI instead of an all-gather before and an all-reduce
 after the evaluation; there is no bulk exchange to overlap.  The temporal pair (i, i+1) is owned, for the loss
@@ -74,11 +77,22 @@ class ShardedFitter:
         f = self.fitter
         names = f.trainable(stage_id)
         if self.world == 1 and not self.always_exchange:
-            f.evaluate(weights, w_temp, stage_id, want=names)
-            f.apply_adam(names, lr)
-            return f.losses
+            return f.step(weights, w_temp, lr, stage_id) if hasattr(f, "run_iterations") else self._plain_step(weights, w_temp, lr, stage_id)
         if not self._halo_valid:
             self.exchange_halos()
+        if hasattr(f, "local_step"):
+            # HIP engine: evaluation + per-frame Adam + record packing are enqueued from the library (two calls), the
+            # collective is the only torch op, the rank-ordered reduction + shared Adam is one more kernel
+            ns = f.num_shared()
+            if self._gather is None or self._gather.numel() != self.world * (ns + 216):
+                dev = f.flat.device
+                self._payload = torch.empty(ns + 216, device=dev, dtype=torch.float32)
+                self._gather = torch.empty(self.world, ns + 216, device=dev, dtype=torch.float32)
+            f.local_step(weights, w_temp, lr, stage_id, self._payload)
+            dist.all_gather_into_tensor(self._gather.view(-1), self._payload, group=self.group)
+            f.shared_step(self._gather, self.world, lr, stage_id)
+            self._set_halos(self._gather[:, ns:].view(self.world, 2, 108))
+            return f.losses
         f.evaluate(weights, w_temp, stage_id, want=names)
         local = tuple(k for k in names if k not in SHARED_NAMES)
         shared = tuple(k for k in names if k in SHARED_NAMES)
@@ -93,13 +107,20 @@ class ShardedFitter:
             self._gather = torch.empty(self.world * (ns + 216), device=sg.device, dtype=sg.dtype)
         self._payload[:ns].copy_(sg)
         self._fill_boundary(self._payload[ns:])
-        dist.all_gather_into_tensor(self._gather, self._payload, group=self.group)
+        dist.all_gather_into_tensor(self._gather.view(-1), self._payload, group=self.group)
         g = self._gather.view(self.world, ns + 216)
         if shared:
             # one reduction kernel over the ranks; every rank runs the same kernel on the same bytes: identical results
             torch.sum(g[:, :ns], dim=0, out=sg)
             f.apply_adam(shared, lr, advance=first)
         self._set_halos(g[:, ns:].view(self.world, 2, 108))
+        return f.losses
+
+    def _plain_step(self, weights, w_temp, lr, stage_id):
+        f = self.fitter
+        names = f.trainable(stage_id)
+        f.evaluate(weights, w_temp, stage_id, want=names)
+        f.apply_adam(names, lr)
         return f.losses
 
     def _fill_boundary(self, out):

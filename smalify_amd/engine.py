@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import FitArgs, ModelDesc, SmalfitError, check
+from ._lib import AdamArgs, FitArgs, ModelDesc, SmalfitError, check
 
 LOSS_NAMES = ("joint", "pose", "splay", "betas", "sil_reproj", "temp_joint", "temp_global", "temp_trans")
 
@@ -104,7 +104,7 @@ class Engine:
               "smalfit_engine_set_shape_prior")
         self.shape_prior_dim = int(m.shape[0])
 
-    SECTIONS = ("lbs_fwd", "raster_sweep", "raster_select", "raster_bwd", "lbs_bwd", "raster_resolve")
+    SECTIONS = ("lbs_fwd", "raster_sweep", "raster_select", "raster_bwd", "lbs_bwd", "raster_resolve", "raster_bbox")
 
     def reset_raster_cache(self):
         """Forget the rasteriser's cached per-pixel depth bounds (affects time only, never results)."""
@@ -116,8 +116,8 @@ class Engine:
 
     def profile_end(self):
         """-> {section: (total_ms, count)} measured with HIP events on the current stream."""
-        ms = (C.c_float * 6)()
-        cnt = (C.c_int * 6)()
+        ms = (C.c_float * len(self.SECTIONS))()
+        cnt = (C.c_int * len(self.SECTIONS))()
         check(self.lib.smalfit_engine_profile_end(self.handle, _stream(), ms, cnt), "smalfit_engine_profile_end")
         return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(self.SECTIONS)}
 
@@ -138,6 +138,24 @@ class Engine:
 
         weights = (w_j2d, w_sil, w_betas, w_pose, w_limit (ignored), w_splay) as in the reference's
         OPT_WEIGHTS columns.  Returns (losses (8,) device tensor, grads dict)."""
+        a, losses, grads, _keep = self.build_fit_args(
+            betas=betas, log_beta_scales=log_beta_scales, global_rotation=global_rotation,
+            joint_rotations=joint_rotations, trans=trans, target_joints=target_joints,
+            target_visibility=target_visibility, target_sil=target_sil, weights=weights, w_temp=w_temp, window=window,
+            temporal=temporal, global_mask=global_mask, rotation_mask=rotation_mask, halo_prev=halo_prev,
+            halo_next=halo_next, losses=losses, grads=grads, want=want, sil_out=sil_out, proj_out=proj_out,
+            verts_out=verts_out)
+        check(self.lib.smalfit_fit_eval(self.handle, _stream(), C.byref(a)), "smalfit_fit_eval")
+        return losses, grads
+
+    def build_fit_args(self, *, betas, log_beta_scales, global_rotation, joint_rotations, trans,
+                       target_joints, target_visibility, target_sil, weights, w_temp, window,
+                       temporal=True, global_mask=None, rotation_mask=None, halo_prev=None, halo_next=None,
+                       losses=None, grads=None, want=("betas", "log_beta_scales", "global_rotation",
+                                                      "joint_rotations", "trans"),
+                       sil_out=None, proj_out=None, verts_out=None):
+        """-> (smalfit_fit_args, losses, grads, keep-alive list): the argument block of smalfit_fit_eval / smalfit_fit_run.
+        The block holds raw device pointers: the caller keeps the tensors alive for as long as it uses it."""
         M = int(global_rotation.shape[0])
         w_j2d, w_sil, w_betas, w_pose, _w_limit, w_splay = [float(w) for w in weights]
         dev = global_rotation.device
@@ -172,8 +190,16 @@ class Engine:
         a.g_joint_rotations = _ptr(grads.get("joint_rotations")) if "joint_rotations" in want else None
         a.g_trans = _ptr(grads.get("trans")) if "trans" in want else None
         a.sil_out, a.proj_out, a.verts_out = _ptr(sil_out), _ptr(proj_out), _ptr(verts_out)
-        check(self.lib.smalfit_fit_eval(self.handle, _stream(), C.byref(a)), "smalfit_fit_eval")
-        return losses, grads
+        keep = [betas, log_beta_scales, global_rotation, joint_rotations, trans, target_joints, target_visibility,
+                target_sil, global_mask, rotation_mask, halo_prev, halo_next, losses, grads, sil_out, proj_out, verts_out]
+        return a, losses, grads, keep
+
+    def fit_run(self, fit_args, adam_args, iterations):
+        """`iterations` x (evaluation + backward + Adam step) in one call (smalfit_fit_run; reference
+        optimize_to_joints.py:113-137).  Advances adam_args.step."""
+        check(self.lib.smalfit_fit_run(self.handle, _stream(), C.byref(fit_args), C.byref(adam_args), int(iterations)),
+              "smalfit_fit_run")
+        adam_args.step += int(iterations)
 
     # ---- SMAL.__call__ ---------------------------------------------------------------------------
     def lbs_forward(self, beta, theta, logscale=None, want_Rs=True, want_v_shaped=True):
@@ -304,6 +330,38 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, t, beta1=0.5, beta2=0.999, e
     lib = _lib.load()
     check(lib.smalfit_adam_step(_stream(), int(param.numel()), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
                                 float(lr), float(beta1), float(beta2), float(eps), int(t)), "smalfit_adam_step")
+
+
+def make_adam_args(param, grad, exp_avg, exp_avg_sq, segments, lr, step=0, beta1=0.5, beta2=0.999, eps=1e-8):
+    """smalfit_adam_args over flat float32 device tensors; segments = [(begin, end), ...] (at most 4)"""
+    if len(segments) > 4:
+        raise SmalfitError("at most 4 trainable ranges")
+    a = AdamArgs()
+    a.param, a.grad, a.exp_avg, a.exp_avg_sq = _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq)
+    a.num_segments = len(segments)
+    for k, (b, e) in enumerate(segments):
+        a.seg_begin[k], a.seg_end[k] = int(b), int(e)
+    a.lr, a.beta1, a.beta2, a.eps, a.step = float(lr), float(beta1), float(beta2), float(eps), int(step)
+    return a
+
+
+def adam_segments(adam_args):
+    """one fused Adam launch over the ranges (t = step + 1); advances adam_args.step"""
+    check(_lib.load().smalfit_adam_segments(_stream(), C.byref(adam_args)), "smalfit_adam_segments")
+    adam_args.step += 1
+
+
+def shard_record(num_shared, shared_grad, num_frames, global_rotation, joint_rotations, trans, global_mask, rotation_mask, record):
+    check(_lib.load().smalfit_shard_record(_stream(), int(num_shared), _ptr(shared_grad), int(num_frames), _ptr(global_rotation),
+                                           _ptr(joint_rotations), _ptr(trans), _ptr(global_mask), _ptr(rotation_mask),
+                                           _ptr(record)), "smalfit_shard_record")
+
+
+def shard_reduce_step(world_size, record_stride, gathered, num_shared, num_trainable, adam_args):
+    """sum of the gathered partial shape gradients (rank order) + Adam on the first num_trainable shared parameters;
+    does not advance adam_args.step (the caller does, once per iteration)"""
+    check(_lib.load().smalfit_shard_reduce_step(_stream(), int(world_size), int(record_stride), _ptr(gathered), int(num_shared),
+                                                int(num_trainable), C.byref(adam_args)), "smalfit_shard_reduce_step")
 
 
 # ---- fitter_3d: SMAL-to-mesh objective (SURVEY.md 8f row 3) ------------------------------------------------------

@@ -97,11 +97,11 @@ class FusedFitter:
         return tuple(names)
 
     def begin_stage(self, stage_id):
-        """fresh optimiser state, as `torch.optim.Adam(model.parameters(), ...)` per stage"""
-        self.exp_avg.zero_()
-        self.exp_avg_sq.zero_()
+        """fresh optimiser state, as `torch.optim.Adam(model.parameters(), ...)` per stage.  Nothing is filled: the
+        first Adam step of a stage takes the moments as zero (smalfit_adam_args.step == 0)."""
         self.step_count = 0
         self.stage_id = stage_id
+        self._plan = None
 
     def _segments(self, names):
         """contiguous [start, end) runs of the flat buffer covering the trainable tensors"""
@@ -117,30 +117,89 @@ class FusedFitter:
         return segs
 
     # ---- one epoch (optimize_to_joints.py:113-137) ---------------------------------------------------------
-    def evaluate(self, weights, w_temp, stage_id, want=None, **outs):
+    def _fit_args(self, weights, w_temp, stage_id, want, **outs):
         vis = self.visibility_stage0 if stage_id == 0 else self.visibility_full
+        return self.e.build_fit_args(
+            betas=self.p["betas"], log_beta_scales=self.p["log_beta_scales"],
+            global_rotation=self.p["global_rotation"], joint_rotations=self.p["joint_rotations"],
+            trans=self.p["trans"], target_joints=self.target_joints, target_visibility=vis,
+            target_sil=self.target_sil, weights=weights, w_temp=w_temp, window=self.window,
+            temporal=True, global_mask=self.global_mask, rotation_mask=self.rotation_mask,
+            halo_prev=self.halo_prev, halo_next=self.halo_next,
+            losses=self.losses, grads=self.g, want=want, **outs)
+
+    def evaluate(self, weights, w_temp, stage_id, want=None, **outs):
         want = self.trainable(stage_id) if want is None else want
-        self.e.fit_eval(betas=self.p["betas"], log_beta_scales=self.p["log_beta_scales"],
-                        global_rotation=self.p["global_rotation"], joint_rotations=self.p["joint_rotations"],
-                        trans=self.p["trans"], target_joints=self.target_joints, target_visibility=vis,
-                        target_sil=self.target_sil, weights=weights, w_temp=w_temp, window=self.window,
-                        temporal=True, global_mask=self.global_mask, rotation_mask=self.rotation_mask,
-                        halo_prev=self.halo_prev, halo_next=self.halo_next,
-                        losses=self.losses, grads=self.g, want=want, **outs)
+        a, _, _, _keep = self._fit_args(weights, w_temp, stage_id, want, **outs)
+        eng.check(self.e.lib.smalfit_fit_eval(self.e.handle, eng._stream(), eng.C.byref(a)), "smalfit_fit_eval")
         return self.losses
+
+    def _adam_args(self, names, lr):
+        return eng.make_adam_args(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self._segments(names), lr,
+                                  step=self.step_count)
 
     def apply_adam(self, names, lr, advance=True):
-        """Adam on the trainable tensors `names`; advance=False: a second group of tensors within the same iteration"""
-        if advance:
-            self.step_count += 1
-        for s, t in self._segments(names):
-            eng.adam_step(self.flat[s:t], self.grad[s:t], self.exp_avg[s:t], self.exp_avg_sq[s:t], lr, self.step_count)
+        """Adam on the trainable tensors `names` (one launch); advance=False: a second group of tensors within the
+        same iteration"""
+        a = self._adam_args(names, lr)
+        if not advance:
+            a.step -= 1
+        eng.adam_segments(a)
+        self.step_count = a.step
+
+    def _stage_plan(self, weights, w_temp, lr, stage_id, names):
+        """argument blocks of the stage's iterations, rebuilt only when something they depend on changes"""
+        key = (tuple(float(w) for w in weights), float(w_temp), float(lr), stage_id, tuple(names),
+               None if self.halo_prev is None else self.halo_prev.data_ptr(),
+               None if self.halo_next is None else self.halo_next.data_ptr())
+        if getattr(self, "_plan", None) is None or self._plan[0] != key:
+            fa, _, _, keep = self._fit_args(weights, w_temp, stage_id, names)
+            self._plan = (key, fa, self._adam_args(names, lr), keep)
+        self._plan[2].step = self.step_count
+        return self._plan[1], self._plan[2]
+
+    def run_iterations(self, weights, w_temp, lr, stage_id, iterations):
+        """`iterations` epochs of the reference loop in ONE library call (smalfit_fit_run): evaluation + analytic
+        backward + Adam, all enqueued from C"""
+        fa, aa = self._stage_plan(weights, w_temp, lr, stage_id, self.trainable(stage_id))
+        self.e.fit_run(fa, aa, iterations)
+        self.step_count = aa.step
+        return self.losses
 
     def step(self, weights, w_temp, lr, stage_id):
+        return self.run_iterations(weights, w_temp, lr, stage_id, 1)
+
+    # ---- frame-sharded protocol (smalify_amd/distributed.py) ----------------------------------------------------
+    def num_shared(self):
+        return 20 + (6 if self.ls_shared else 0)
+
+    def local_step(self, weights, w_temp, lr, stage_id, record):
+        """evaluation + Adam on the per-frame parameters + this rank's record (partial shared gradient | boundary
+        frames after the step) written into `record` (num_shared() + 216 floats)"""
         names = self.trainable(stage_id)
-        self.evaluate(weights, w_temp, stage_id, want=names)
-        self.apply_adam(names, lr)
-        return self.losses
+        local = tuple(k for k in names if k not in ("betas", "log_beta_scales") or (k == "log_beta_scales" and not self.ls_shared))
+        key = (tuple(float(w) for w in weights), float(w_temp), float(lr), stage_id, tuple(names), "sharded",
+               None if self.halo_prev is None else self.halo_prev.data_ptr(),
+               None if self.halo_next is None else self.halo_next.data_ptr())
+        if getattr(self, "_plan", None) is None or self._plan[0] != key:
+            fa, _, _, keep = self._fit_args(weights, w_temp, stage_id, names)
+            self._plan = (key, fa, self._adam_args(local, lr), keep)
+        fa, aa = self._plan[1], self._plan[2]
+        aa.step = self.step_count
+        self.e.fit_run(fa, aa, 1)
+        eng.shard_record(self.num_shared(), self.grad, self.N, self.p["global_rotation"], self.p["joint_rotations"],
+                         self.p["trans"], self.global_mask, self.rotation_mask, record)
+
+    def shared_step(self, gathered, world_size, lr, stage_id):
+        """sum of the ranks' partial shared gradients + Adam on the shared parameters the stage trains; closes the
+        iteration (advances the step count)"""
+        names = self.trainable(stage_id)
+        ntrain = 0
+        if "betas" in names:
+            ntrain = 20 + (6 if (self.ls_shared and "log_beta_scales" in names) else 0)
+        aa = eng.make_adam_args(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, [], lr, step=self.step_count)
+        eng.shard_reduce_step(world_size, gathered.shape[-1], gathered, self.num_shared(), ntrain, aa)
+        self.step_count += 1
 
     def shared_grad(self):
         """view of the gradient of the parameters every frame shares (betas, and the limb scales when shared)"""

@@ -339,6 +339,46 @@ def case_sil_trajectory(M=4, S=64, window=2, iters=8, seed=21):
     return out
 
 
+def case_full_schedule(M=4, S=64, window=2, iters_scale=0.1, seed=21):
+    """All four stages of the reference schedule (config.OPT_WEIGHTS: weights, learning rates, stage-0 freeze and torso
+    keypoints, fresh Adam per stage), iteration counts scaled by `iters_scale`: FusedFitter on the GPU (one library call
+    per stage) against the oracle's loss + autograd + Adam on the CPU from the same start.  Returns the final per-term
+    losses of both, their relative differences, and the end-of-run relative L2 difference of every parameter tensor
+    (checks (iii) and (iv))."""
+    from smalify_amd import fitter as fit
+    W = np.array(cfg.OPT_WEIGHTS).T
+    e, prob, cur, tg = make_problem(M, S, window, seed)
+    sched = [max(1, int(round(int(w[7]) * iters_scale))) for w in W]
+    # oracle loop (optimize_to_joints.py:90-137)
+    params = {k: torch.from_numpy(v).double() for k, v in cur.items()}
+    sums_o = {}
+    for stage, w in enumerate(W):
+        weights, w_temp, lr = w[:6].copy(), float(w[6]), float(w[8])
+        names = so.trainable_names(stage)
+        vis = so.stage0_visibility(prob.vis) if stage == 0 else None
+        opt = so.Adam(so.PARAM_ORDER, lr=lr)
+        for _ in range(sched[stage]):
+            total, sums_o, grads = so.loss_and_grads(prob, params, weights, w_temp, names, visibility=vis)
+            opt.step(params, grads)
+    # device loop
+    f = fit.FusedFitter(e, tg["tj"], tg["vis"], tg["tsil"], window, True, cur["betas"], cur["log_beta_scales"])
+    for k in ("global_rotation", "joint_rotations", "trans"):
+        f.p[k].copy_(dev(cur[k]))
+    for stage, w in enumerate(W):
+        f.begin_stage(stage)
+        f.run_iterations(w[:6].copy(), float(w[6]), float(w[8]), stage, sched[stage])
+    l = f.losses.cpu().numpy().astype(np.float64)
+    out = {"schedule": sched, "status": e.status(), "final_total_oracle": float(sum(sums_o.values())), "final_total_hip": float(l.sum())}
+    out["final_total_rel"] = abs(out["final_total_hip"] - out["final_total_oracle"]) / abs(out["final_total_oracle"])
+    for i, nme in enumerate(eng.LOSS_NAMES):
+        ref = float(sums_o.get(nme, 0.0))
+        out["final_%s_oracle" % nme], out["final_%s_hip" % nme] = ref, float(l[i])
+        out["final_%s_rel" % nme] = abs(l[i] - ref) / max(abs(ref), 1e-12)
+    for k in ("betas", "log_beta_scales", "global_rotation", "joint_rotations", "trans"):
+        out["param_%s_rel_l2" % k] = rel(f.p[k].cpu().numpy().reshape(params[k].shape), params[k].numpy())
+    return out
+
+
 def case_fit_family0_512(golden, M=2, S=512, window=2, stage=2, seed=43):
     """BASELINE config 5's ingredients in one evaluation: a non-unity shape family (20-dim SMAL cluster prior from the
     reference's golden data, per-frame (N,6) limb scales without a regulariser), 512 x 512 silhouettes, stage-2 weights."""

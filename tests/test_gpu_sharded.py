@@ -51,10 +51,14 @@ def _factory(pc, cur, tg, lo, hi):
     return f
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _worker(rank, world, port, q, backend="gloo"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "nccl":                       # RCCL: one GPU per rank
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         q.put((rank, _run(_factory, rank, world)))
         dist.barrier()
@@ -63,11 +67,42 @@ def _worker(rank, world, port, q):
 
 
 def test_two_ranks_on_one_gpu_match_the_unsharded_fit():
+    _two_ranks("gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL collective needs one GPU per rank")
+def test_two_ranks_over_rccl_match_the_unsharded_fit():
+    """the same comparison with the record travelling over RCCL (backend "nccl") between two GPUs"""
+    _two_ranks("nccl")
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` outside a launcher starts N ranks itself and reports n_gpus = N: checked with N = 2 when a
+    second GPU is visible; on a one-GPU box the launcher + RCCL initialisation + sharded step run with a world of one rank
+    (SMALFIT_BENCH_FORCE_DIST)"""
+    import json
+    import subprocess
+    n = 2 if torch.cuda.device_count() >= 2 else 1
+    env = dict(os.environ, SMALFIT_BENCH_FORCE_DIST="1")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "12", "--warmup", "4", "--no-cpu-baseline"]
+    if n == 1:                                   # exercise the launcher + RCCL initialisation with a world of one rank
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(29400 + os.getpid() % 500)] + cmd[1:]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["steps"] == 12 and d["value"] > 0 and d["status_bits"] == 0
+
+
+def _two_ranks(backend):
     single = _run(_factory, 0, 1)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29700 + (os.getpid() % 1000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     got = {}
