@@ -26,7 +26,7 @@ typedef struct smalfit_engine smalfit_engine;
 #define SMALFIT_NUM_JOINTS 35
 #define SMALFIT_NUM_MODEL_JOINTS 41
 #define SMALFIT_NUM_KEYPOINTS 25
-#define SMALFIT_NUM_LOSS_TERMS 8 /* joint, pose, splay, betas, sil_reproj, temp_joint, temp_global, temp_trans */
+#define SMALFIT_NUM_LOSS_TERMS 9 /* joint, pose, splay, betas, sil_reproj, temp_joint, temp_global, temp_trans, limit */
 
 #define SMALFIT_STATUS_BIN_OVERFLOW 1 /* reserved */
 
@@ -83,6 +83,10 @@ int smalfit_engine_profile_end(smalfit_engine* engine, void* stream, float* ms_t
  * host arrays: prec (105,105), mean (105), mask (105) */
 int smalfit_engine_set_pose_prior(smalfit_engine* engine, const float* prec, const float* mean,
                                   const float* mask);
+/* replaces: LimitPrior().min_values / max_values viewed as (N_POSE, 3)   reference smal_fitter/smal_fitter.py:76-79,
+ * priors/joint_limits_prior.py:39-104 (commented out upstream: its table has 32 joints x 3 where view(34, 3) expects 34;
+ * smalify_amd/model_io.py::joint_limit_table completes it).  host arrays: min (34,3), max (34,3), min <= max */
+int smalfit_engine_set_joint_limits(smalfit_engine* engine, const float* min_values, const float* max_values);
 /* replaces: betas_prec / mean_betas          reference smal_fitter/smal_fitter.py:48-69
  * host arrays: prec (dim,dim), mean (dim); dim = 26 (unity prior: betas|log scales) or <= 20 */
 int smalfit_engine_set_shape_prior(smalfit_engine* engine, const float* prec, const float* mean, int dim);
@@ -156,7 +160,7 @@ typedef struct smalfit_fit_args {
   const float* target_sil;        /* (M,S,S); may be NULL when w_sil == 0                       */
   const float* halo_prev;         /* (108,) masked theta(105)|trans(3) of the frame before frame 0, or NULL */
   const float* halo_next;         /* (108,) of the frame after frame M-1, or NULL               */
-  float* losses;                  /* (8,) see SMALFIT_NUM_LOSS_TERMS                            */
+  float* losses;                  /* (9,) see SMALFIT_NUM_LOSS_TERMS                            */
   float* g_betas;                 /* (20,)           or NULL                                    */
   float* g_log_beta_scales;       /* (6,) / (M,6)    or NULL                                    */
   float* g_global_rotation;       /* (M,3)           or NULL                                    */
@@ -165,6 +169,11 @@ typedef struct smalfit_fit_args {
   float* sil_out;                 /* (M,S,S) rendered silhouettes or NULL                       */
   float* proj_out;                /* (M,25,2) projected keypoints or NULL                       */
   float* verts_out;               /* (M,V,3) translated vertices or NULL                        */
+  const unsigned char* target_sil_u8; /* (M,S,S) target silhouettes as bytes, t = b / 255 (what the 8-bit masks of
+                                     data_loader.py:43 hold); used instead of target_sil when not NULL          */
+  float w_limit;                  /* joint-limit hinge weight (OPT_WEIGHTS row 5).  Ignored -- like the reference, whose
+                                     term is commented out while its weight table says 100 -- until
+                                     smalfit_engine_set_joint_limits has been called                          */
 } smalfit_fit_args;
 
 int smalfit_fit_eval(smalfit_engine* engine, void* stream, const smalfit_fit_args* args);

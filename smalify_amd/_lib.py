@@ -40,7 +40,7 @@ class FitArgs(C.Structure):
                 ("g_betas", C.c_void_p), ("g_log_beta_scales", C.c_void_p),
                 ("g_global_rotation", C.c_void_p), ("g_joint_rotations", C.c_void_p),
                 ("g_trans", C.c_void_p), ("sil_out", C.c_void_p), ("proj_out", C.c_void_p),
-                ("verts_out", C.c_void_p)]
+                ("verts_out", C.c_void_p), ("target_sil_u8", C.c_void_p), ("w_limit", C.c_float)]
 
 
 class AdamArgs(C.Structure):
@@ -81,6 +81,7 @@ SIGNATURES = {
     "smalfit_engine_profile_end": (_I, [_VP, _VP, _VP, _VP]),
     "smalfit_engine_set_pose_prior": (_I, [_VP, _VP, _VP, _VP]),
     "smalfit_engine_set_shape_prior": (_I, [_VP, _VP, _VP, _I]),
+    "smalfit_engine_set_joint_limits": (_I, [_VP, _VP, _VP]),
     "smalfit_lbs_forward": (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "smalfit_lbs_backward": (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "smalfit_rodrigues": (_I, [_VP, _I, _VP, _VP]),

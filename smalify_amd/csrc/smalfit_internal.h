@@ -57,6 +57,9 @@ struct LossArgs {
   const float* tj;         // [M][25][2] (row, col)
   const float* vis;        // [M][25]
   float w_j2d, w_pose, w_splay, w_temp;
+  float w_limit;           // joint-limit hinge (smal_fitter.py:146-151)
+  const float* lim_min;    // [102] lower / upper limit per joint-rotation component
+  const float* lim_max;
   const float* pose_prec;  // [105][105]
   const float* pose_mean;  // [105]
   const float* pose_mask;  // [105]

@@ -13,7 +13,8 @@ import torch
 from . import _lib
 from ._lib import AdamArgs, FitArgs, ModelDesc, SmalfitError, check
 
-LOSS_NAMES = ("joint", "pose", "splay", "betas", "sil_reproj", "temp_joint", "temp_global", "temp_trans")
+LOSS_NAMES = ("joint", "pose", "splay", "betas", "sil_reproj", "temp_joint", "temp_global", "temp_trans", "limit")
+NUM_LOSS_TERMS = len(LOSS_NAMES)
 
 
 def _ptr(t):
@@ -22,6 +23,12 @@ def _ptr(t):
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
         raise SmalfitError("expected a contiguous float32 device tensor, got %r" % (
             (t.dtype, t.device, t.is_contiguous()) if isinstance(t, torch.Tensor) else type(t),))
+    return C.c_void_p(t.data_ptr())
+
+
+def _ptr_u8(t):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
+        raise SmalfitError("expected a contiguous uint8 device tensor")
     return C.c_void_p(t.data_ptr())
 
 
@@ -104,6 +111,12 @@ class Engine:
               "smalfit_engine_set_shape_prior")
         self.shape_prior_dim = int(m.shape[0])
 
+    def set_joint_limits(self, min_values, max_values):
+        """(34,3) lower / upper limits of the joint rotations for the w_limit term (reference smal_fitter.py:76-79,146-151)"""
+        lo, hi = _host(min_values, np.float32).reshape(-1), _host(max_values, np.float32).reshape(-1)
+        assert lo.shape == (102,) and hi.shape == (102,)
+        check(self.lib.smalfit_engine_set_joint_limits(self.handle, lo.ctypes.data, hi.ctypes.data), "smalfit_engine_set_joint_limits")
+
     SECTIONS = ("lbs_fwd", "raster_sweep", "raster_select", "raster_bwd", "lbs_bwd", "raster_resolve", "raster_bbox")
 
     def reset_raster_cache(self):
@@ -136,8 +149,9 @@ class Engine:
                  sil_out=None, proj_out=None, verts_out=None):
         """One evaluation of sum_windows SMALFitter.forward + get_temporal and its gradient.
 
-        weights = (w_j2d, w_sil, w_betas, w_pose, w_limit (ignored), w_splay) as in the reference's
-        OPT_WEIGHTS columns.  Returns (losses (8,) device tensor, grads dict)."""
+        weights = (w_j2d, w_sil, w_betas, w_pose, w_limit, w_splay) as in the reference's OPT_WEIGHTS columns
+        (w_limit > 0 needs set_joint_limits).  target_sil: float32 (M,S,S), or uint8 bytes b = 255 t.
+        Returns (losses (9,) device tensor in LOSS_NAMES order, grads dict)."""
         a, losses, grads, _keep = self.build_fit_args(
             betas=betas, log_beta_scales=log_beta_scales, global_rotation=global_rotation,
             joint_rotations=joint_rotations, trans=trans, target_joints=target_joints,
@@ -157,10 +171,12 @@ class Engine:
         """-> (smalfit_fit_args, losses, grads, keep-alive list): the argument block of smalfit_fit_eval / smalfit_fit_run.
         The block holds raw device pointers: the caller keeps the tensors alive for as long as it uses it."""
         M = int(global_rotation.shape[0])
-        w_j2d, w_sil, w_betas, w_pose, _w_limit, w_splay = [float(w) for w in weights]
+        w_j2d, w_sil, w_betas, w_pose, w_limit, w_splay = [float(w) for w in weights]
         dev = global_rotation.device
         if losses is None:
-            losses = torch.empty(8, device=dev, dtype=torch.float32)
+            losses = torch.empty(NUM_LOSS_TERMS, device=dev, dtype=torch.float32)
+        elif losses.numel() < NUM_LOSS_TERMS:
+            raise SmalfitError("losses must hold %d floats" % NUM_LOSS_TERMS)
         if grads is None:
             grads = {}
         params = dict(betas=betas, log_beta_scales=log_beta_scales, global_rotation=global_rotation,
@@ -181,7 +197,12 @@ class Engine:
         a.betas, a.log_beta_scales = _ptr(betas), _ptr(log_beta_scales)
         a.global_rotation, a.joint_rotations, a.trans = _ptr(global_rotation), _ptr(joint_rotations), _ptr(trans)
         a.global_mask, a.rotation_mask = _ptr(global_mask), _ptr(rotation_mask)
-        a.target_joints, a.target_visibility, a.target_sil = _ptr(target_joints), _ptr(target_visibility), _ptr(target_sil)
+        a.target_joints, a.target_visibility = _ptr(target_joints), _ptr(target_visibility)
+        if target_sil is not None and target_sil.dtype == torch.uint8:
+            a.target_sil, a.target_sil_u8 = None, _ptr_u8(target_sil)
+        else:
+            a.target_sil, a.target_sil_u8 = _ptr(target_sil), None
+        a.w_limit = w_limit
         a.halo_prev, a.halo_next = _ptr(halo_prev), _ptr(halo_next)
         a.losses = _ptr(losses)
         a.g_betas = _ptr(grads.get("betas")) if "betas" in want else None

@@ -36,7 +36,7 @@ class FusedFitter:
 
     def __init__(self, engine: eng.Engine, target_joints, target_visibility, target_sil, window_size,
                  use_unity_prior=True, mean_betas=None, mean_log_scales=None, allow_limb_scaling=True,
-                 rank=0, world_size=1, group=None):
+                 rank=0, world_size=1, group=None, sil_storage="auto"):
         self.e = engine
         dev = engine.device
         self.N = int(target_joints.shape[0])
@@ -55,6 +55,20 @@ class FusedFitter:
         self.target_joints = to_dev(target_joints)
         self.visibility_full = to_dev(target_visibility)
         self.target_sil = to_dev(target_sil).reshape(self.N, self.S, self.S).contiguous()
+        # Device-resident targets as bytes when that loses nothing: the masks the reference's loaders read are 8-bit
+        # images / 255 (data_loader.py:43), and a binary mask stays binary through the crop.  b / 255 in the kernels is the
+        # correctly rounded quotient, i.e. exactly the float32 value such a mask holds -> bit-identical results, a quarter
+        # of the target traffic.  Masks with other values (bilinear resampling of the crop) stay float32.
+        if sil_storage not in ("auto", "f32", "u8"):
+            raise ValueError("sil_storage must be 'auto', 'f32' or 'u8'")
+        if sil_storage != "f32":
+            q = torch.round(self.target_sil * 255.0)
+            exact = bool(((q / 255.0) == self.target_sil).all()) and bool(((q >= 0) & (q <= 255)).all())
+            if exact:
+                self.target_sil_f32 = self.target_sil if sil_storage == "u8" else None
+                self.target_sil = q.to(torch.uint8).contiguous()
+            elif sil_storage == "u8":
+                raise ValueError("target silhouettes are not multiples of 1/255: they cannot be stored as bytes exactly")
         vis0 = torch.zeros_like(self.visibility_full)
         vis0[:, config.TORSO_JOINTS] = self.visibility_full[:, config.TORSO_JOINTS]
         self.visibility_stage0 = vis0.contiguous()
@@ -83,9 +97,16 @@ class FusedFitter:
         self.p["global_rotation"].copy_(torch.as_tensor(model_io.initial_global_rotation(), **f32)[None].expand(N, 3))
         self.global_mask = torch.ones(3, **f32)
         self.rotation_mask = torch.ones(34, 3, **f32)
-        self.losses = torch.zeros(8, **f32)
+        self.losses = torch.zeros(eng.NUM_LOSS_TERMS, **f32)
         self.step_count = 0
         self.halo_prev = self.halo_next = None
+
+    def enable_joint_limits(self, min_values=None, max_values=None):
+        """switch on the joint-limit hinge the reference has commented out (smal_fitter.py:76-79,146-151): from then on
+        the w_limit column of the weight table (100 in stages 1-3, config.py:68) takes effect on this engine"""
+        if min_values is None:
+            min_values, max_values = model_io.joint_limit_table()
+        self.e.set_joint_limits(min_values, max_values)
 
     # ---- stage control (optimize_to_joints.py:96-110) --------------------------------------------------
     def trainable(self, stage_id):
@@ -224,6 +245,22 @@ class FusedFitter:
         torch.mul(rec, self._brec_mask, out=out)
         return out.view(2, 108)
 
+    def snapshot(self):
+        """-> (verts (N,V,3) translated, silhouettes (N,S,S), projected keypoints (N,25,2)) at the current parameters.
+        Forward only, into scratch buffers: the fit's loss vector and gradients are left alone."""
+        dev = self.flat.device
+        V = self.e.model.num_verts
+        verts = torch.empty(self.N, V, 3, device=dev)
+        sil = torch.empty(self.N, self.S, self.S, device=dev)
+        proj = torch.empty(self.N, 25, 2, device=dev)
+        self.e.fit_eval(betas=self.p["betas"], log_beta_scales=self.p["log_beta_scales"],
+                        global_rotation=self.p["global_rotation"], joint_rotations=self.p["joint_rotations"],
+                        trans=self.p["trans"], target_joints=None, target_visibility=None, target_sil=None,
+                        weights=(0, 0, 0, 0, 0, 0), w_temp=0.0, window=self.window, temporal=False,
+                        global_mask=self.global_mask, rotation_mask=self.rotation_mask,
+                        losses=torch.empty(eng.NUM_LOSS_TERMS, device=dev), grads={}, want=(), sil_out=sil, proj_out=proj, verts_out=verts)
+        return verts, sil, proj
+
     def run_schedule(self, opt_weights=None, iters_scale=1.0, on_visualize=None, vis_frequency=None):
         """The reference's full stage loop. Returns per-stage final loss vectors (host)."""
         W = np.array(config.OPT_WEIGHTS if opt_weights is None else opt_weights).T
@@ -232,10 +269,17 @@ class FusedFitter:
         for stage_id, w in enumerate(W):
             weights, w_temp, epochs, lr = w[:6], float(w[6]), max(1, int(round(int(w[7]) * iters_scale))), float(w[8])
             self.begin_stage(stage_id)
-            for epoch_id in range(epochs):
-                self.step(weights, w_temp, lr, stage_id)
+            epoch_id = 0
+            while epoch_id < epochs:
+                # up to the next visualisation epoch (or the end of the stage) in one library call
+                if on_visualize is None:
+                    n = epochs - epoch_id
+                else:
+                    n = min(epochs - epoch_id, 1 if epoch_id % vis_frequency == 0 else vis_frequency - epoch_id % vis_frequency)
+                self.run_iterations(weights, w_temp, lr, stage_id, n)
                 if on_visualize is not None and epoch_id % vis_frequency == 0:
                     on_visualize(self, stage_id, epoch_id)
+                epoch_id += n
             history.append(self.losses.cpu().numpy().copy())
         return history
 

@@ -157,6 +157,7 @@ class Stage:
         self._objective = _objective_for(fit, N_SAMPLE_POINTS)
         self._buffers = {}
         self._points = None
+        self._last_points = None
         self.seed = int(seed)
         self.iteration_offset = int(iteration_offset)      # global iteration of this stage's first step (StageManager)
         self._loss_history = torch.zeros(max(self.n_it, 1), device=self.device)
@@ -173,8 +174,8 @@ class Stage:
 
     @property
     def last_points(self):
-        """the target points of the most recent evaluation, (N, 3000, 3)"""
-        return self._points
+        """the target points of the most recent evaluation or step, (N, 3000, 3)"""
+        return self._last_points if self._last_points is not None else self._points
 
     @property
     def last_terms(self):
@@ -193,8 +194,8 @@ class Stage:
         theta = fit._pack_theta()
         lbs = e.lbs_forward(betas, theta, ls, want_Rs=False, want_v_shaped=False)[0]
         if points is None and self.loss_weights["w_chamfer"] > 0:
-            points = self.target_meshes.sample(N_SAMPLE_POINTS, self.seed, self.iteration_offset + iteration, out=self._points)
-        self._points = points
+            points = self.target_meshes.sample(N_SAMPLE_POINTS, self.seed, self.iteration_offset + iteration, out=self._sample_buffer())
+        self._last_points = points            # the sampler's buffer is never rebound: smalfit_fit3d_step writes through its raw pointer
         o = self._objective.eval(lbs, fit.trans.detach().contiguous(), fit.deform_verts.detach().contiguous(), points,
                                  self._weights(), out=self._buffers)
         self._buffers = o
@@ -222,6 +223,7 @@ class Stage:
         dev_targets = getattr(self.target_meshes, "_dev", self.target_meshes)
         eng.check(e.lib.smalfit_fit3d_step(e.handle, self._objective.handle, dev_targets.handle, eng._stream(), C.byref(a)),
                   "smalfit_fit3d_step")
+        self._last_points = self._points
         return self._buffers["losses"][4]
 
     def step_unfused(self, epoch):
@@ -236,6 +238,13 @@ class Stage:
             p.grad = g
             eng.adam_step(p.data, g, st["m"], st["v"], st["lr"], self._t, beta1=0.9, beta2=0.999, eps=1e-8)
         return loss
+
+    def _sample_buffer(self):
+        """the one (N, 3000, 3) tensor the sampler writes into, allocated once and kept for the life of the stage (the cached
+        argument block of step() holds its device pointer)"""
+        if self._points is None:
+            self._points = torch.empty(self.smal_3d_fitter.batch_size, N_SAMPLE_POINTS, 3, device=self.device)
+        return self._points
 
     def _step_args(self):
         if self._args is None:
@@ -253,11 +262,9 @@ class Stage:
             a.beta1, a.beta2, a.eps = 0.9, 0.999, 1e-8
             a.points = None
             a.seed = self.seed & (2 ** 64 - 1)
-            if self._points is None:
-                self._points = torch.empty(N, N_SAMPLE_POINTS, 3, device=self.device)
             if "losses" not in self._buffers:
                 self._buffers["losses"] = torch.zeros(5, device=self.device)
-            a.points_out = self._points.data_ptr()
+            a.points_out = self._sample_buffer().data_ptr()
             a.losses = self._buffers["losses"].data_ptr()
             a.verts_out = None
             self._args = a

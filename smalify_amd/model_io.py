@@ -216,3 +216,55 @@ def initial_global_rotation():
     axis = np.array([m[2, 1] - m[1, 2], m[0, 2] - m[2, 0], m[1, 0] - m[0, 1]])
     axis = axis / np.linalg.norm(axis)
     return (axis * angle).astype(np.float64)
+
+
+# reference smal_fitter/priors/joint_limits_prior.py:3-37 `Ranges` in the order of its part ids 0..31 (:41-74) = SMAL joints
+# 1..32 = rows 0..31 of joint_rotations: [x_min, x_max], [y_min, y_max], [z_min, z_max] per joint
+_JOINT_RANGES = (
+    ((-0.3, 0.3), (-1.2, 0.5), (-0.1, 0.1)),      # pelvis0
+    ((-0.4, 0.4), (-1.0, 0.9), (-0.8, 0.8)),      # spine
+    ((-0.4, 0.4), (-1.0, 0.9), (-0.8, 0.8)),      # spine0
+    ((-0.4, 0.4), (-0.5, 1.2), (-0.4, 0.4)),      # spine1
+    ((-0.5, 0.5), (-0.4, 1.4), (-0.5, 0.5)),      # spine2
+    ((-0.5, 0.5), (-0.6, 1.4), (-0.8, 0.8)),      # spine3
+    ((-0.05, 0.05), (-1.3, 0.8), (-0.6, 0.6)),    # LLeg1
+    ((-0.05, 0.05), (-1.0, 1.1), (-0.6, 0.6)),    # LLeg2
+    ((-0.4, 0.1), (-0.3, 1.4), (-0.7, 0.4)),      # LLeg3
+    ((-0.3, 0.1), (-0.4, 1.5), (-0.7, 0.3)),      # LFoot
+    ((-0.05, 0.05), (-1.3, 0.8), (-0.6, 0.6)),    # RLeg1
+    ((-0.05, 0.05), (-1.0, 0.9), (-0.6, 0.6)),    # RLeg2
+    ((-0.1, 0.4), (-0.3, 1.4), (-0.4, 0.7)),      # RLeg3
+    ((-0.1, 0.3), (-0.4, 1.5), (-0.3, 0.7)),      # RFoot
+    ((-0.8, 0.8), (-1.0, 1.0), (-1.1, 1.1)),      # Neck
+    ((-0.5, 0.5), (-1.0, 0.9), (-0.9, 0.9)),      # Head
+    ((-0.2, 0.3), (-0.5, 0.8), (-0.5, 0.4)),      # LLegBack1
+    ((-0.2, 0.3), (-0.6, 0.8), (-0.6, 0.5)),      # LLegBack2
+    ((-0.3, 0.2), (-0.8, 0.2), (-0.5, 0.4)),      # LLegBack3
+    ((-0.3, 0.2), (-0.3, 1.1), (-0.5, 0.3)),      # LFootBack
+    ((-0.3, 0.2), (-0.5, 0.8), (-0.4, 0.5)),      # RLegBack1
+    ((-0.3, 0.2), (-0.6, 0.8), (-0.5, 0.6)),      # RLegBack2
+    ((-0.2, 0.3), (-0.8, 0.2), (-0.4, 0.5)),      # RLegBack3
+    ((-0.2, 0.3), (-0.3, 1.1), (-0.3, 0.5)),      # RFootBack
+    ((-0.1, 0.1), (-1.5, 1.4), (-1.2, 1.2)),      # Tail1
+    ((-0.1, 0.1), (-1.0, 1.0), (-0.8, 0.8)),      # Tail2
+    ((-0.1, 0.1), (-1.0, 1.0), (-0.8, 0.8)),      # Tail3
+    ((-0.1, 0.1), (-1.0, 1.0), (-0.8, 0.8)),      # Tail4
+    ((-0.1, 0.1), (-1.0, 1.0), (-0.8, 0.8)),      # Tail5
+    ((-0.1, 0.1), (-1.4, 1.4), (-1.0, 1.0)),      # Tail6
+    ((-0.1, 0.1), (-0.7, 1.1), (-0.9, 0.8)),      # Tail7
+    ((-0.1, 0.1), (-1.1, 0.5), (-0.1, 0.1)),      # Mouth
+)
+
+
+def joint_limit_table():
+    """-> (min (34,3), max (34,3)) float32 for SMALFitter's w_limit term (reference smal_fitter.py:76-79, 146-151).
+
+    The reference builds LimitPrior().min_values / max_values (32 joints x 3 = 96 numbers, joint_limits_prior.py:76-83) and
+    views them as (N_POSE, 3) = (34, 3) -- which cannot work, and the code is commented out.  Here the 32 limited joints
+    keep the prior's own order (part ids 0..31 = SMAL joints 1..32 = joint_rotations rows 0..31) and the two joints the
+    table does not know (33, 34: the ears) are unconstrained."""
+    lo = np.full((34, 3), -np.inf, np.float32)
+    hi = np.full((34, 3), np.inf, np.float32)
+    r = np.asarray(_JOINT_RANGES, np.float32)            # (32, 3, 2)
+    lo[:32], hi[:32] = r[:, :, 0], r[:, :, 1]
+    return lo, hi

@@ -82,20 +82,38 @@ def fit_sequence(data, filenames, model_data, pose_prior, shape_prior, use_unity
     engine.set_pose_prior(*pose_prior)
     engine.set_shape_prior(*shape_prior)
     f = fit.FusedFitter(engine, joints, vis, sil, window_size or config.WINDOW_SIZE, use_unity_prior,
-                        mean_betas=shape_prior[1][:20], mean_log_scales=shape_prior[1][20:26] if use_unity_prior else None)
+                        mean_betas=shape_prior[1][:20], mean_log_scales=shape_prior[1][20:26] if use_unity_prior else None,
+                        allow_limb_scaling=config.ALLOW_LIMB_SCALING)
     exporter = ImageExporter(output_dir, filenames) if output_dir else None
+    rgb_dev = torch.as_tensor(np.asarray(rgb), dtype=torch.float32, device=engine.device)
+    rot_y180 = torch.tensor([[-1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, -1.0]], device=engine.device)
+    colour = [c / 255.0 for c in config.MESH_COLOR]
 
     def export(fitter, stage_id, epoch_id):
+        """the reference's ImageExporter output per frame (optimize_to_joints.py:43-53): st{stage}_ep{epoch}.png (the
+        five-panel collage of smal_fitter.py:226-266), .pkl, .ply -- from a forward-only snapshot, the fit's losses untouched"""
         if exporter is None:
             return
-        verts = torch.empty(fitter.N, dm.num_verts, 3, device=engine.device)
-        W = np.array(config.OPT_WEIGHTS if opt_weights is None else opt_weights).T
-        fitter.evaluate(W[min(stage_id, 3)][:6], 0.0, min(stage_id, 3), want=(), verts_out=verts)
-        for d, params, v in zip(exporter.output_dirs, fitter.frame_parameters(), verts.cpu().numpy()):
+        from .smal_fitter import SMALFitter
+        verts, sil_r, proj = fitter.snapshot()
+        rendered = engine.render_color(verts, colour)
+        centre = verts.mean(dim=1, keepdim=True)
+        back = ((verts - centre) @ rot_y180.T).contiguous()
+        rev_rendered = engine.render_color(back, colour)
+        # keypoints of the turned mesh: the canonical joints are vertices-independent here, so mark the front view's only
+        overlay = rendered * 0.8 + rgb_dev * 0.2
+        sil_err = (1.0 - (fitter.target_sil - sil_r).abs()).unsqueeze(1).expand(-1, 3, -1, -1).cpu()
+        vis_t = fitter.visibility_full
+        collage = torch.cat([SMALFitter._draw_joints(rgb_dev, fitter.target_joints, vis_t),
+                             SMALFitter._draw_joints(rendered, proj, vis_t), SMALFitter._draw_joints(overlay, proj, vis_t),
+                             sil_err, rev_rendered.cpu()], dim=3)
+        v_np = verts.cpu().numpy()
+        for i, (d, params) in enumerate(zip(exporter.output_dirs, fitter.frame_parameters())):
             stem = os.path.join(d, "st{0}_ep{1}".format(stage_id, epoch_id))
+            write_png(stem + ".png", (np.transpose(collage[i].numpy(), (1, 2, 0)) * 255.0).astype(np.uint8))
             with open(stem + ".pkl", "wb") as fh:
                 pkl.dump(params, fh)
-            write_ply(stem + ".ply", v, model_data.faces)
+            write_ply(stem + ".ply", v_np[i], model_data.faces)
 
     f.run_schedule(opt_weights, iters_scale, on_visualize=export)
     export(f, 10, 0)                                   # final stage (optimize_to_joints.py:142-144)

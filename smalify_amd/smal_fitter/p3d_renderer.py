@@ -9,6 +9,7 @@ colour image of the reference's second renderer (hard rasterisation + HardPhongS
 config.MESH_COLOR, white background; smalfit_render_color) -- visualisation only, it carries no gradient."""
 from __future__ import annotations
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -66,10 +67,22 @@ class Renderer(nn.Module):
                   "smalfit_render_forward")
         return proj
 
+    def _check_faces(self, faces, e):
+        """the rasteriser always draws the topology registered with the engine: refuse anything else (checked by content
+        once per faces tensor, then by identity)"""
+        key = (faces.data_ptr(), tuple(faces.shape), faces._version)
+        if getattr(self, "_faces_ok", None) == key:
+            return
+        f = faces.reshape(-1, faces.shape[-2], 3)[0] if faces.dim() > 2 else faces
+        ref = torch.as_tensor(np.asarray(e.model.data.faces), device=f.device)
+        if tuple(f.shape) != tuple(ref.shape) or not bool((f.to(ref.dtype) == ref).all()):
+            raise ValueError("faces do not match the SMAL topology the rasteriser was built for")
+        self._faces_ok = key
+
     def forward(self, vertices, points, faces, render_texture=False):
         e = self._engine(vertices.shape[0])
-        if faces is not None and faces.shape[-2] != e.model.num_faces:
-            raise ValueError("faces do not match the SMAL topology the rasteriser was built for")
+        if faces is not None:
+            self._check_faces(faces, e)
         sil = _Silhouette.apply(self, vertices)
         proj = _Project.apply(self, points)
         if render_texture:

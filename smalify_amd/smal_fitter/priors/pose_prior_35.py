@@ -44,5 +44,4 @@ class Prior(object):
         return e
 
     def __call__(self, x):
-        shape = x.shape
-        return _PriorFn.apply(self, x.reshape(-1, 105)).reshape(shape[0] if len(shape) > 1 else 1, 105)
+        return _PriorFn.apply(self, x.reshape(-1, 105))        # (-1, 105) for any input layout, like the reference (:117)

@@ -50,7 +50,7 @@ class _WindowLoss(torch.autograd.Function):
         ctx.saved = (grads, idx, per_frame_ls, global_rotation.shape, joint_rotations.shape, trans.shape,
                      log_beta_scales.shape)
         ctx.mark_non_differentiable(losses)
-        return losses[:5].sum(), losses
+        return losses[:5].sum() + losses[8], losses          # the window's terms (temporal is separate); [8] = joint limits
 
     @staticmethod
     def backward(ctx, gtotal, _glosses):
@@ -86,10 +86,12 @@ class _Temporal(torch.autograd.Function):
 
 class SMALFitter(nn.Module):
     def __init__(self, device, data_batch, batch_size, shape_family, use_unity_prior, model_data=None,
-                 pose_prior_data=None, shape_prior_data=None):
+                 pose_prior_data=None, shape_prior_data=None, enable_joint_limits=False):
         """model_data / pose_prior_data / shape_prior_data let tests inject the synthetic stand-ins; by default
-        everything is read from the paths in smalify_amd.config exactly like the reference (smal_fitter.py:40-74)."""
+        everything is read from the paths in smalify_amd.config exactly like the reference (smal_fitter.py:40-74).
+        enable_joint_limits: switch on the w_limit term the reference has commented out (smal_fitter.py:76-79,146-151)."""
         super().__init__()
+        self.enable_joint_limits = bool(enable_joint_limits)
         self.rgb_imgs, self.sil_imgs, self.target_joints, self.target_visibility = data_batch
         dev = torch.device("cuda", torch.cuda.current_device())
         self.target_visibility = self.target_visibility.long().to(dev)
@@ -135,15 +137,22 @@ class SMALFitter(nn.Module):
         if getattr(e, "_fitter_priors", None) is not self:
             e.set_pose_prior(*self.pose_prior._data)
             e.set_shape_prior(*self._shape_prior)
+            if self.enable_joint_limits:                            # reference smal_fitter.py:76-79, commented out there
+                e.set_joint_limits(*model_io.joint_limit_table())
             e._pose_prior, e._shape_prior, e._fitter_priors = self.pose_prior._data, self._shape_prior, self
         return e
 
     def forward(self, batch_range, weights, stage_id):
         total, losses = _WindowLoss.apply(self, list(batch_range), [float(w) for w in weights], self.betas,
                                           self.log_beta_scales, self.global_rotation, self.joint_rotations, self.trans)
-        w_j2d, w_reproj, w_betas, w_pose, _w_limit, w_splay = [float(w) for w in weights]
+        w_j2d, w_reproj, w_betas, w_pose, w_limit, w_splay = [float(w) for w in weights]
         active = dict(joint=w_j2d > 0, pose=w_pose > 0, splay=w_splay > 0, betas=w_betas > 0, sil_reproj=w_reproj > 0)
-        objs = {k: losses[i] for i, k in enumerate(_TERMS) if active[k]}
+        objs = {}
+        for i, k in enumerate(_TERMS):
+            if active[k]:
+                objs[k] = losses[i]
+            if k == "joint" and w_limit > 0 and self.enable_joint_limits:   # the reference's (disabled) term order: joint, limit, pose, ...
+                objs["limit"] = losses[8]
         return total, objs
 
     def get_temporal(self, w_temp):

@@ -339,6 +339,53 @@ def case_sil_trajectory(M=4, S=64, window=2, iters=8, seed=21):
     return out
 
 
+def case_fit_limits(M=3, S=64, window=2, seed=23, w_limit=40.0):
+    """the joint-limit hinge term (reference smal_fitter.py:146-151 with the table of priors/joint_limits_prior.py): one
+    stage-1-type evaluation without silhouette, w_limit switched on, HIP vs oracle"""
+    W = np.array(cfg.OPT_WEIGHTS).T
+    weights = W[1][:6].copy()
+    weights[1] = 0.0                      # no silhouette: this case is about the limit term
+    weights[4] = w_limit
+    w_temp = float(W[1][6])
+    e, prob, cur, tg = make_problem(M, S, window, seed, with_sil=False)
+    lo, hi = model_io.joint_limit_table()
+    e.set_joint_limits(lo, hi)
+    prob.limits = (torch.from_numpy(lo).double(), torch.from_numpy(hi).double())
+    names = so.PARAM_ORDER
+    params64 = {k: torch.from_numpy(v).double() for k, v in cur.items()}
+    total, sums, grads_o = so.loss_and_grads(prob, params64, weights, w_temp, names)
+    d = {k: dev(v) for k, v in cur.items()}
+    losses, grads = e.fit_eval(betas=d["betas"], log_beta_scales=d["log_beta_scales"], global_rotation=d["global_rotation"],
+                               joint_rotations=d["joint_rotations"], trans=d["trans"], target_joints=dev(tg["tj"]),
+                               target_visibility=dev(tg["vis"]), target_sil=None, weights=weights, w_temp=w_temp, window=window, want=names)
+    l = losses.cpu().numpy().astype(np.float64)
+    out = {"status": e.status(), "limit_oracle": sums["limit"], "limit_hip": float(l[8]),
+           "total_rel": abs(l.sum() - float(total)) / abs(float(total))}
+    for k in names:
+        out["grad_%s_rel" % k] = rel(grads[k].cpu().numpy(), grads_o[k].numpy())
+    return out
+
+
+def case_u8_targets(M=8, S=128, window=4, iters=6, seed=29):
+    """the same short fit with the target silhouettes resident as float32 and as bytes: every parameter and every loss term
+    must come out bit-identical (binary masks: b / 255 is exactly 0 or 1)"""
+    from smalify_amd import fitter as fit
+    W = np.array(cfg.OPT_WEIGHTS).T
+    e, prob, cur, tg = make_problem(M, S, window, seed)
+    res = {}
+    for storage in ("f32", "u8"):
+        e.reset_raster_cache()
+        f = fit.FusedFitter(e, tg["tj"], tg["vis"], tg["tsil"], window, True, cur["betas"], cur["log_beta_scales"], sil_storage=storage)
+        for k in ("global_rotation", "joint_rotations", "trans"):
+            f.p[k].copy_(dev(cur[k]))
+        f.begin_stage(2)
+        f.run_iterations(W[2][:6], float(W[2][6]), float(W[2][8]), 2, iters)
+        res[storage] = (f.flat.cpu().numpy().copy(), f.losses.cpu().numpy().copy(), f.target_sil.dtype)
+    return {"dtype_f32": str(res["f32"][2]), "dtype_u8": str(res["u8"][2]),
+            "params_identical": bool(np.array_equal(res["f32"][0], res["u8"][0])),
+            "losses_identical": bool(np.array_equal(res["f32"][1], res["u8"][1])), "status": e.status()}
+
+
 def case_full_schedule(M=4, S=64, window=2, iters_scale=0.1, seed=21):
     """All four stages of the reference schedule (config.OPT_WEIGHTS: weights, learning rates, stage-0 freeze and torso
     keypoints, fresh Adam per stage), iteration counts scaled by `iters_scale`: FusedFitter on the GPU (one library call

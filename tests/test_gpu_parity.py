@@ -148,3 +148,22 @@ def test_full_schedule(capsys):
     for k, v in m.items():
         if k.startswith("param_"):
             assert v < 2e-2, (k, v)
+
+
+def test_joint_limit_term():
+    """the reference's disabled w_limit hinge, built behind the weight row it already has"""
+    m = pc.case_fit_limits()
+    assert m["status"] == 0
+    assert m["limit_oracle"] > 0.05, m                    # the perturbed pose does leave the limits
+    assert abs(m["limit_hip"] - m["limit_oracle"]) < 1e-5 * m["limit_oracle"], m
+    assert m["total_rel"] < 1e-5, m
+    for k, v in m.items():
+        if k.startswith("grad_"):
+            assert v < 5e-4, (k, v)
+
+
+def test_byte_resident_targets_are_bit_identical():
+    """device-resident u8 silhouette targets give the float32 path's bits"""
+    m = pc.case_u8_targets()
+    assert m["dtype_f32"] == "torch.float32" and m["dtype_u8"] == "torch.uint8", m
+    assert m["status"] == 0 and m["params_identical"] and m["losses_identical"], m

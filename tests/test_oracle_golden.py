@@ -174,3 +174,24 @@ def test_adam_trajectory_matches_reference_loop(golden, synth_model):
             ref = golden["g8_after_stage%d_%s" % (stage, k)]
             assert rel(params[k].numpy(), ref) < 2e-4, (stage, k, rel(params[k].numpy(), ref))
     assert np.allclose(hist, golden["g8_loss_history"], rtol=2e-4)
+
+
+def test_joint_limit_term_known_answer(synth_model):
+    """w_limit hinge (reference smal_fitter.py:146-151): flat inside the limits, |x - limit| outside, mean over (B, 34, 3)"""
+    import torch
+    from oracle import smal_oracle as so
+    from smalify_amd import model_io, synthetic
+    lo, hi = model_io.joint_limit_table()
+    om = so.OracleModel(synth_model)
+    pp, sp = synthetic.synthetic_pose_prior(), synthetic.synthetic_shape_prior()
+    B = 2
+    prob = so.FitProblem(om, 32, np.zeros((B, 25, 2)), np.zeros((B, 25)), np.zeros((B, 32, 32)), pp[0], pp[1], pp[2], sp[0], sp[1],
+                         B, True, joint_limits=(lo, hi))
+    jr = torch.zeros(B, 34, 3, dtype=torch.float64)
+    jr[0, 6, 0] = 0.30           # LLeg1 x: limits +-0.05 -> 0.25 over
+    jr[1, 24, 1] = -1.9          # Tail1 y: lower limit -1.5 -> 0.4 under
+    jr[1, 33, 2] = 7.0           # an ear: not in the reference's table -> unconstrained
+    params = dict(betas=torch.zeros(20, dtype=torch.float64), log_beta_scales=torch.zeros(6, dtype=torch.float64),
+                  global_rotation=torch.zeros(B, 3, dtype=torch.float64), joint_rotations=jr, trans=torch.zeros(B, 3, dtype=torch.float64))
+    _, terms = so.window_loss(prob, params, [0, 1], (0, 0, 0, 0, 10.0, 0))
+    assert abs(float(terms["limit"]) - 10.0 * (0.25 + 0.4) / (B * 102)) < 1e-8      # the table is float32
