@@ -173,11 +173,16 @@ class FusedFitter:
         key = (tuple(float(w) for w in weights), float(w_temp), float(lr), stage_id, tuple(names),
                None if self.halo_prev is None else self.halo_prev.data_ptr(),
                None if self.halo_next is None else self.halo_next.data_ptr())
-        if getattr(self, "_plan", None) is None or self._plan[0] != key:
+        plans = self._plan if isinstance(getattr(self, "_plan", None), dict) else {}
+        if key not in plans:
+            if len(plans) > 4:
+                plans.clear()
             fa, _, _, keep = self._fit_args(weights, w_temp, stage_id, names)
-            self._plan = (key, fa, self._adam_args(names, lr), keep)
-        self._plan[2].step = self.step_count
-        return self._plan[1], self._plan[2]
+            plans[key] = (fa, self._adam_args(names, lr), keep)
+        self._plan = plans
+        fa, aa, _ = plans[key]
+        aa.step = self.step_count
+        return fa, aa
 
     def run_iterations(self, weights, w_temp, lr, stage_id, iterations):
         """`iterations` epochs of the reference loop in ONE library call (smalfit_fit_run): evaluation + analytic
@@ -202,10 +207,14 @@ class FusedFitter:
         key = (tuple(float(w) for w in weights), float(w_temp), float(lr), stage_id, tuple(names), "sharded",
                None if self.halo_prev is None else self.halo_prev.data_ptr(),
                None if self.halo_next is None else self.halo_next.data_ptr())
-        if getattr(self, "_plan", None) is None or self._plan[0] != key:
+        plans = self._plan if isinstance(getattr(self, "_plan", None), dict) else {}
+        if key not in plans:
+            if len(plans) > 4:
+                plans.clear()
             fa, _, _, keep = self._fit_args(weights, w_temp, stage_id, names)
-            self._plan = (key, fa, self._adam_args(local, lr), keep)
-        fa, aa = self._plan[1], self._plan[2]
+            plans[key] = (fa, self._adam_args(local, lr), keep)
+        self._plan = plans
+        fa, aa, _ = plans[key]
         aa.step = self.step_count
         self.e.fit_run(fa, aa, 1)
         eng.shard_record(self.num_shared(), self.grad, self.N, self.p["global_rotation"], self.p["joint_rotations"],

@@ -28,6 +28,8 @@ def main():
             e.profile_begin(20)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(20):
+                if os.environ.get("PROBE_COLD") == "1":        # every evaluation selects every bounded pixel from scratch
+                    e.reset_raster_cache()
                 f.evaluate(W[2][:6], float(W[2][6]), 2)
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
             sec = e.profile_end()
