@@ -30,6 +30,9 @@ GROUPS = [
 
 
 def main():
+    global GROUPS
+    if os.environ.get("PMC_GROUPS"):                 # e.g. PMC_GROUPS='[["TCP_TOTAL_CACHE_ACCESSES","TCP_TCC_READ_REQ"],["TA_BUSY"]]'
+        GROUPS = json.loads(os.environ["PMC_GROUPS"])
     tag = sys.argv[1] if len(sys.argv) > 1 else "pmc_sq"
     bench_args = sys.argv[2:] or ["--steps", "39", "--warmup", "4", "--no-cpu-baseline"]
     out = os.path.join(ROOT, "gpurun_out", tag)
@@ -39,7 +42,7 @@ def main():
     open(os.path.join(out, "counters_list.txt"), "w").write(listing)
     summary = {}
     for gi, group in enumerate(GROUPS):
-        names = [c for c in group if c in listing] or group
+        names = [c for c in group if (c + " ") in listing or (c + "\n") in listing or ("Name: " + c) in listing or c in listing] or group
         d = os.path.join(out, "g%d" % gi)
         cmd = ["rocprofv3", "--pmc"] + names + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                                                 sys.executable, os.path.join(ROOT, "bench.py")] + bench_args
