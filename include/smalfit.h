@@ -200,6 +200,10 @@ typedef struct smalfit_adam_args {
 } smalfit_adam_args;
 int smalfit_fit_run(smalfit_engine* engine, void* stream, const smalfit_fit_args* args, const smalfit_adam_args* adam,
                     int iterations);
+/* enable != 0: smalfit_fit_run captures one iteration (the evaluation's kernels + the Adam launch) into a HIP graph the
+ * first time it sees a set of arguments on a (non-default) stream and replays it `iterations` times; the Adam step count
+ * then lives in a device counter and the bias corrections are formed on the device.  Off by default. */
+int smalfit_engine_set_graph(smalfit_engine* engine, int enable);
 /* optimizer.step() alone on the ranges (t = adam->step + 1) */
 int smalfit_adam_segments(void* stream, const smalfit_adam_args* adam);
 

@@ -93,6 +93,7 @@ SIGNATURES = {
     "smalfit_project_points_backward": (_I, [_VP, _I, _I, _VP, _VP, _VP]),
     "smalfit_fit_eval": (_I, [_VP, _VP, C.POINTER(FitArgs)]),
     "smalfit_fit_run": (_I, [_VP, _VP, C.POINTER(FitArgs), C.POINTER(AdamArgs), _I]),
+    "smalfit_engine_set_graph": (_I, [_VP, _I]),
     "smalfit_adam_segments": (_I, [_VP, C.POINTER(AdamArgs)]),
     "smalfit_shard_record": (_I, [_VP, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "smalfit_shard_reduce_step": (_I, [_VP, _I, _I, _VP, _I, _I, C.POINTER(AdamArgs)]),

@@ -111,6 +111,10 @@ class Engine:
               "smalfit_engine_set_shape_prior")
         self.shape_prior_dim = int(m.shape[0])
 
+    def set_graph(self, enable=True):
+        """replay one captured iteration per fit_run step (HIP graph) instead of enqueueing its launches one by one"""
+        check(self.lib.smalfit_engine_set_graph(self.handle, int(bool(enable))), "smalfit_engine_set_graph")
+
     def set_joint_limits(self, min_values, max_values):
         """(34,3) lower / upper limits of the joint rotations for the w_limit term (reference smal_fitter.py:76-79,146-151)"""
         lo, hi = _host(min_values, np.float32).reshape(-1), _host(max_values, np.float32).reshape(-1)

@@ -177,3 +177,29 @@ def test_fit_non_unity_family_with_per_frame_limb_scales_at_512(golden):
     for k, v in m.items():
         if k.startswith("grad_"):
             assert v < 2e-3, (k, v, m)
+
+
+def test_graph_replay_gives_the_same_bits_as_individual_launches():
+    """smalfit_engine_set_graph: one captured iteration replayed per step (Adam's step count in a device counter, bias
+    corrections formed on the device) ends in the same parameters and losses as the launch-by-launch loop"""
+    from smalify_amd import config as cfg, fitter as fit
+    W = np.array(cfg.OPT_WEIGHTS).T
+    e, prob, cur, tg = pc.make_problem(8, 64, 4, 31)
+    out = []
+    side = torch.cuda.Stream()
+    for graph in (False, True):
+        e.set_graph(graph)
+        e.reset_raster_cache()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            f = fit.FusedFitter(e, tg["tj"], tg["vis"], tg["tsil"], 4, True, cur["betas"], cur["log_beta_scales"])
+            for k in ("global_rotation", "joint_rotations", "trans"):
+                f.p[k].copy_(pc.dev(cur[k]))
+            for stage, its in ((0, 3), (1, 5), (2, 4)):
+                f.begin_stage(stage)
+                f.run_iterations(W[stage][:6], float(W[stage][6]), float(W[stage][8]), stage, its)
+            side.synchronize()
+            out.append((f.flat.cpu().numpy().copy(), f.losses.cpu().numpy().copy()))
+    e.set_graph(False)
+    assert e.status() == 0
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
