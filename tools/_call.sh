@@ -1,2 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for n in 1 8; do python tools/rank_sim.py $n 390 2>&1 | tail -2; RANK_SIM_GRAPH=1 python tools/rank_sim.py $n 390 2>&1 | tail -2; done
+O=gpurun_out/c15; mkdir -p $O
+python -m pytest tests -x -q -m gpu > $O/pytest.txt 2>&1
+tail -12 $O/pytest.txt
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | cut -c1-900
