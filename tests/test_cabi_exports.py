@@ -41,7 +41,8 @@ def test_struct_layouts_match_the_header(tmp_path):
     same field names, offsets and total size (guards against the ctypes mirror drifting from the header)"""
     import ctypes as C
     import subprocess
-    pairs = {"smalfit_model_desc": _lib.ModelDesc, "smalfit_fit_args": _lib.FitArgs, "smalfit_fit3d_args": _lib.Fit3dArgs}
+    pairs = {"smalfit_model_desc": _lib.ModelDesc, "smalfit_fit_args": _lib.FitArgs, "smalfit_fit3d_args": _lib.Fit3dArgs,
+             "smalfit_adam_args": _lib.AdamArgs}
     lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "smalfit.h"', "int main(void) {"]
     for cname, cls in pairs.items():
         lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
