@@ -104,6 +104,27 @@ int smalfit_lbs_backward(smalfit_engine* engine, void* stream, int M, int nb, co
                          const float* theta, const float* logscale, const float* dverts,
                          const float* djoints, float* dbeta, float* dtheta, float* dlogscale);
 
+/* the same call with every option of the reference's signature (smal_torch.py:99):
+ *   SMAL.__call__(beta, theta, trans=None, del_v=None, betas_logscale=None, get_skin=True, v_template=None)
+ * theta as (M,35,3) axis-angles OR Rs as (M,35,3,3) rotation matrices (:132-133, `len(theta.shape) == 4`);
+ * v_offset (M,V,3) is added to the shaped template: del_v, plus (v_template - the model's template) for a per-call
+ * template (:107-122).  trans is a plain addition after the call.  Forward reads the inputs and writes verts / joints
+ * (+ Rs_out, v_shaped when not NULL); backward recomputes the forward and reads dverts / djoints (either may be NULL),
+ * writing whichever of dbeta, dtheta (axis-angle input) or dRs (matrix input), dlogscale, dv_offset is not NULL. */
+typedef struct smalfit_lbs_args {
+  int num_frames, num_betas;
+  const float* beta;       /* (M,nb)                          */
+  const float* theta;      /* (M,35,3) or NULL when Rs given  */
+  const float* Rs;         /* (M,35,3,3) or NULL              */
+  const float* logscale;   /* (M,6) or NULL                   */
+  const float* v_offset;   /* (M,V,3) or NULL                 */
+  float *verts, *joints, *Rs_out, *v_shaped;            /* forward outputs: (M,V,3), (M,41,3), (M,35,3,3), (M,V,3) */
+  const float *dverts, *djoints;                        /* backward inputs                                          */
+  float *dbeta, *dtheta, *dRs, *dlogscale, *dv_offset;  /* backward outputs                                         */
+} smalfit_lbs_args;
+int smalfit_lbs_forward_ex(smalfit_engine* engine, void* stream, const smalfit_lbs_args* args);
+int smalfit_lbs_backward_ex(smalfit_engine* engine, void* stream, const smalfit_lbs_args* args);
+
 /* ---- batch_rodrigues ----------------------------------------------------------------------------
  * replaces: batch_rodrigues(theta)                           reference smal_model/batch_lbs.py:33-52 */
 int smalfit_rodrigues(void* stream, int count, const float* theta, float* R);

@@ -43,6 +43,12 @@ class FitArgs(C.Structure):
                 ("verts_out", C.c_void_p), ("target_sil_u8", C.c_void_p), ("w_limit", C.c_float)]
 
 
+class LbsArgs(C.Structure):
+    _fields_ = [("num_frames", C.c_int), ("num_betas", C.c_int)] + [(n, C.c_void_p) for n in (
+        "beta", "theta", "Rs", "logscale", "v_offset", "verts", "joints", "Rs_out", "v_shaped", "dverts", "djoints",
+        "dbeta", "dtheta", "dRs", "dlogscale", "dv_offset")]
+
+
 class AdamArgs(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("num_segments", C.c_int), ("seg_begin", C.c_int * 4), ("seg_end", C.c_int * 4),
@@ -84,6 +90,8 @@ SIGNATURES = {
     "smalfit_engine_set_joint_limits": (_I, [_VP, _VP, _VP]),
     "smalfit_lbs_forward": (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "smalfit_lbs_backward": (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "smalfit_lbs_forward_ex": (_I, [_VP, _VP, C.POINTER(LbsArgs)]),
+    "smalfit_lbs_backward_ex": (_I, [_VP, _VP, C.POINTER(LbsArgs)]),
     "smalfit_rodrigues": (_I, [_VP, _I, _VP, _VP]),
     "smalfit_rodrigues_backward": (_I, [_VP, _I, _VP, _VP, _VP]),
     "smalfit_global_rigid_transformation": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _VP, _VP]),

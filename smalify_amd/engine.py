@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import AdamArgs, FitArgs, ModelDesc, SmalfitError, check
+from ._lib import AdamArgs, FitArgs, LbsArgs, ModelDesc, SmalfitError, check
 
 LOSS_NAMES = ("joint", "pose", "splay", "betas", "sil_reproj", "temp_joint", "temp_global", "temp_trans", "limit")
 NUM_LOSS_TERMS = len(LOSS_NAMES)
@@ -227,7 +227,9 @@ class Engine:
         adam_args.step += int(iterations)
 
     # ---- SMAL.__call__ ---------------------------------------------------------------------------
-    def lbs_forward(self, beta, theta, logscale=None, want_Rs=True, want_v_shaped=True):
+    def lbs_forward(self, beta, theta, logscale=None, want_Rs=True, want_v_shaped=True, v_offset=None):
+        """SMAL.__call__ (smalfit_lbs_forward_ex): theta (M,35,3) axis-angles or (M,35,3,3) rotation matrices; v_offset (M,V,3)
+        is the reference's del_v (+ a per-call v_template's difference to the model's)"""
         M, nb = int(theta.shape[0]), int(beta.shape[1])
         V = self.model.num_verts
         dev = theta.device
@@ -235,20 +237,38 @@ class Engine:
         joints = torch.empty(M, 41, 3, device=dev)
         Rs = torch.empty(M, 35, 3, 3, device=dev) if want_Rs else None
         vs = torch.empty(M, V, 3, device=dev) if want_v_shaped else None
-        check(self.lib.smalfit_lbs_forward(self.handle, _stream(), M, nb, _ptr(beta), _ptr(theta), _ptr(logscale),
-                                           _ptr(verts), _ptr(joints), _ptr(Rs), _ptr(vs)), "smalfit_lbs_forward")
+        a = LbsArgs()
+        a.num_frames, a.num_betas = M, nb
+        a.beta, a.logscale, a.v_offset = _ptr(beta), _ptr(logscale), _ptr(v_offset)
+        if theta.dim() == 4:
+            a.Rs = _ptr(theta)
+        else:
+            a.theta = _ptr(theta)
+        a.verts, a.joints, a.Rs_out, a.v_shaped = _ptr(verts), _ptr(joints), _ptr(Rs), _ptr(vs)
+        check(self.lib.smalfit_lbs_forward_ex(self.handle, _stream(), C.byref(a)), "smalfit_lbs_forward_ex")
         return verts, joints, Rs, vs
 
-    def lbs_backward(self, beta, theta, logscale, dverts, djoints):
+    def lbs_backward(self, beta, theta, logscale, dverts, djoints, v_offset=None):
+        """-> (dbeta, dtheta (or dRs for matrix input), dlogscale) and, when v_offset is given, dv_offset as a 4th value"""
         M, nb = int(theta.shape[0]), int(beta.shape[1])
         dev = theta.device
         dbeta = torch.empty(M, nb, device=dev)
-        dtheta = torch.empty(M, 35, 3, device=dev)
+        dth = torch.empty_like(theta)
         dls = torch.empty(M, 6, device=dev) if logscale is not None else None
-        check(self.lib.smalfit_lbs_backward(self.handle, _stream(), M, nb, _ptr(beta), _ptr(theta), _ptr(logscale),
-                                            _ptr(dverts), _ptr(djoints), _ptr(dbeta), _ptr(dtheta), _ptr(dls)),
-              "smalfit_lbs_backward")
-        return dbeta, dtheta, dls
+        doff = torch.empty_like(v_offset) if v_offset is not None else None
+        a = LbsArgs()
+        a.num_frames, a.num_betas = M, nb
+        a.beta, a.logscale, a.v_offset = _ptr(beta), _ptr(logscale), _ptr(v_offset)
+        if theta.dim() == 4:
+            a.Rs, a.dRs = _ptr(theta), _ptr(dth)
+        else:
+            a.theta, a.dtheta = _ptr(theta), _ptr(dth)
+        a.dverts, a.djoints = _ptr(dverts), _ptr(djoints)
+        a.dbeta, a.dlogscale, a.dv_offset = _ptr(dbeta), _ptr(dls), _ptr(doff)
+        check(self.lib.smalfit_lbs_backward_ex(self.handle, _stream(), C.byref(a)), "smalfit_lbs_backward_ex")
+        if v_offset is not None:
+            return dbeta, dth, dls, doff
+        return dbeta, dth, dls
 
     # ---- Renderer -----------------------------------------------------------------------------------
     def render_forward(self, verts, points=None, want_sil=True):

@@ -4,8 +4,8 @@
          betas_logscale=None, get_skin=True, v_template=None) -> verts, joints, Rs, v_shaped | joints
 
 Blend shapes, Rodrigues, the 34-step kinematic chain, skinning and joint regression are HIP kernels
-(smalfit_lbs_forward / smalfit_lbs_backward); gradients flow to beta, theta and betas_logscale through
-`verts` and `joints` (Rs and v_shaped are returned detached)."""
+(smalfit_lbs_forward_ex / smalfit_lbs_backward_ex); gradients flow to beta, theta (axis-angles or rotation matrices),
+betas_logscale, del_v and v_template through `verts` and `joints` (Rs and v_shaped are returned detached)."""
 from __future__ import annotations
 
 import numpy as np
@@ -17,25 +17,27 @@ from .. import config, engine as eng, model_io, runtime
 
 class _LBS(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, owner, beta, theta, logscale):
+    def forward(ctx, owner, beta, theta, logscale, v_offset):
         e = runtime.get_engine(owner.device_model, theta.shape[0], owner.engine_image_size)
         beta, theta = beta.contiguous().float(), theta.contiguous().float()
         ls = None if logscale is None else logscale.contiguous().float()
-        verts, joints, Rs, vs = e.lbs_forward(beta, theta, ls)
-        ctx.owner, ctx.has_ls = owner, ls is not None
-        ctx.save_for_backward(beta, theta, ls if ls is not None else beta.new_zeros(1))
+        off = None if v_offset is None else v_offset.contiguous().float()
+        verts, joints, Rs, vs = e.lbs_forward(beta, theta, ls, v_offset=off)
+        ctx.owner, ctx.has_ls, ctx.has_off = owner, ls is not None, off is not None
+        ctx.save_for_backward(beta, theta, ls if ls is not None else beta.new_zeros(1), off if off is not None else beta.new_zeros(1))
         ctx.mark_non_differentiable(Rs, vs)
         return verts, joints, Rs, vs
 
     @staticmethod
     def backward(ctx, dverts, djoints, _dRs, _dvs):
-        beta, theta, ls = ctx.saved_tensors
+        beta, theta, ls, off = ctx.saved_tensors
         ls = ls if ctx.has_ls else None
+        off = off if ctx.has_off else None
         e = runtime.get_engine(ctx.owner.device_model, theta.shape[0], ctx.owner.engine_image_size)
         dv = None if dverts is None else dverts.contiguous().float()
         dj = None if djoints is None else djoints.contiguous().float()
-        dbeta, dtheta, dls = e.lbs_backward(beta, theta, ls, dv, dj)
-        return None, dbeta, dtheta, dls
+        out = e.lbs_backward(beta, theta, ls, dv, dj, v_offset=off)
+        return None, out[0], out[1], out[2], (out[3] if off is not None else None)
 
 
 class SMAL(nn.Module):
@@ -64,13 +66,19 @@ class SMAL(nn.Module):
         self.left_inds, self.right_inds, self.center_inds = md.left_inds, md.right_inds, md.center_inds
 
     def __call__(self, beta, theta, trans=None, del_v=None, betas_logscale=None, get_skin=True, v_template=None):
-        if del_v is not None or v_template is not None:
-            raise NotImplementedError("per-call template offsets (del_v / v_template) are used only by the "
-                                      "reference's fitter_3d tool and are not supported by the HIP path")
-        if theta.dim() == 4:
-            raise NotImplementedError("theta must be axis-angle (N,35,3); rotation-matrix input is not supported")
-        theta = theta.reshape(theta.shape[0], 35, 3)
-        verts, joints, Rs, v_shaped = _LBS.apply(self, beta, theta, betas_logscale)
+        # per-call template / offset (smal_torch.py:107-122): v_shaped = v_template + del_v + shape blend.  The engine adds
+        # one per-frame offset to its own template; gradients flow to del_v and to a v_template that requires them
+        N = beta.shape[0]
+        offset = None
+        if v_template is not None:
+            offset = (v_template - self.v_template).expand(N, self.size[0], 3)
+        if del_v is not None:
+            offset = del_v.expand(N, self.size[0], 3) if offset is None else offset + del_v
+        if theta.dim() == 4:                               # rotation matrices (:132-133)
+            theta = theta.reshape(N, 35, 3, 3)
+        else:
+            theta = theta.reshape(N, 35, 3)
+        verts, joints, Rs, v_shaped = _LBS.apply(self, beta, theta, betas_logscale, offset)
         if trans is not None:
             verts = verts + trans[:, None, :]          # reference adds trans after skinning (smal_torch.py:165-168)
             # joints are regressed from the translated vertices in the reference (smal_torch.py:171-184)

@@ -58,6 +58,36 @@ def test_smal_module_matches_reference_golden(golden, md):
     assert smal.faces.shape == (7774, 3) and smal.faces.dtype == torch.int64
 
 
+@pytest.mark.parametrize("tag", ["delv", "vtmpl", "both", "rs"])
+def test_smal_call_options_match_the_reference(md, tag):
+    """SMAL.__call__(del_v=..., v_template=..., theta as (N,35,3,3) rotation matrices) -- smal_torch.py:99-133 -- against values
+    and gradients of the reference's own SMAL (tests/golden/reference_golden_smal_options.npz)"""
+    from smalify_amd.smal_model.smal_torch import SMAL
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_golden_smal_options.npz")))
+    smal = SMAL("cuda", shape_family_id=1, model_data=md)
+    t = lambda a: torch.tensor(np.asarray(a), device="cuda", requires_grad=True)  # noqa: E731
+    beta, ls = t(g["beta"]), t(g["ls"])
+    theta = t(g["Rs"]) if tag == "rs" else t(g["theta"])
+    kw = {}
+    if tag in ("delv", "both"):
+        kw["del_v"] = t(g["del_v"])
+    if tag in ("vtmpl", "both"):
+        kw["v_template"] = t(g["v_template"])
+    verts, joints, Rs, v_shaped = smal(beta, theta, betas_logscale=ls, **kw)
+    vsel = torch.from_numpy(g["vsel"]).cuda()
+    assert rel(verts[:, vsel].detach().cpu(), g[tag + "_verts"]) < 1e-5
+    assert rel(joints.detach().cpu(), g[tag + "_joints"]) < 1e-5
+    assert rel(v_shaped[:, vsel].cpu(), g[tag + "_vshaped"]) < 1e-5
+    func = (verts[:, vsel] * torch.from_numpy(g["wv"]).cuda()).sum() + (joints * torch.from_numpy(g["wj"]).cuda()).sum()
+    func.backward()
+    assert rel(beta.grad.cpu(), g[tag + "_dbeta"]) < 2e-4 and rel(ls.grad.cpu(), g[tag + "_dls"]) < 2e-4
+    assert rel(theta.grad.cpu(), g[tag + ("_dRs" if tag == "rs" else "_dtheta")]) < 2e-4
+    if "del_v" in kw:
+        assert rel(kw["del_v"].grad[:, vsel].cpu(), g[tag + "_ddel_v"]) < 2e-4
+    if "v_template" in kw:
+        assert rel(kw["v_template"].grad[vsel].cpu(), g[tag + "_dv_template"]) < 2e-4
+
+
 def test_batch_rodrigues_matches_reference_golden(golden):
     from smalify_amd.smal_model.batch_lbs import batch_rodrigues
     R = batch_rodrigues(torch.from_numpy(golden["g1_theta"]).cuda())
@@ -261,7 +291,7 @@ def test_fit_sequence_runs_the_schedule_and_writes_the_final_files(golden, md, t
     assert f.e.status() == 0
     for i in range(N):
         stem = os.path.join(str(tmp_path), "frame_%02d" % i, "st10_ep0")
-        assert os.path.exists(stem + ".pkl") and os.path.exists(stem + ".ply")
+        assert os.path.exists(stem + ".pkl") and os.path.exists(stem + ".ply") and os.path.exists(stem + ".png")
         with open(stem + ".pkl", "rb") as fh:
             d = pickle.load(fh)
         assert d["joint_rotations"].shape == (34, 3) and d["joint_rotations"].dtype == np.float32

@@ -195,3 +195,37 @@ def test_joint_limit_term_known_answer(synth_model):
                   global_rotation=torch.zeros(B, 3, dtype=torch.float64), joint_rotations=jr, trans=torch.zeros(B, 3, dtype=torch.float64))
     _, terms = so.window_loss(prob, params, [0, 1], (0, 0, 0, 0, 10.0, 0))
     assert abs(float(terms["limit"]) - 10.0 * (0.25 + 0.4) / (B * 102)) < 1e-8      # the table is float32
+
+
+def _smal_options_golden():
+    import os
+    return dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_golden_smal_options.npz")))
+
+
+@pytest.mark.parametrize("tag", ["delv", "vtmpl", "both", "rs"])
+def test_smal_call_options_against_the_reference(synth_model, tag):
+    """del_v, per-call v_template and rotation-matrix theta of SMAL.__call__ (smal_torch.py:99-133): the oracle against
+    values and gradients produced by the reference's own SMAL (tests/golden/make_golden_smal_options.py)"""
+    import torch
+    from oracle import smal_oracle as so
+    g = _smal_options_golden()
+    om = so.OracleModel(synth_model)
+    t = lambda a: torch.from_numpy(np.asarray(a)).double().requires_grad_(True)  # noqa: E731
+    beta, ls = t(g["beta"]), t(g["ls"])
+    theta = t(g["Rs"]) if tag == "rs" else t(g["theta"])
+    del_v = t(g["del_v"]) if tag in ("delv", "both") else None
+    v_tmpl = t(g["v_template"]) if tag in ("vtmpl", "both") else None
+    verts, joints, _, v_shaped = so.smal_forward(om, beta, theta, ls, del_v=del_v, v_template=v_tmpl)
+    vsel = g["vsel"]
+    func = (verts[:, vsel] * torch.from_numpy(g["wv"]).double()).sum() + (joints * torch.from_numpy(g["wj"]).double()).sum()
+    func.backward()
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / np.linalg.norm(b))  # noqa: E731
+    assert rel(verts.detach().numpy()[:, vsel], g[tag + "_verts"]) < 2e-6
+    assert rel(joints.detach().numpy(), g[tag + "_joints"]) < 2e-6
+    assert rel(v_shaped.detach().numpy()[:, vsel], g[tag + "_vshaped"]) < 2e-6
+    assert rel(beta.grad.numpy(), g[tag + "_dbeta"]) < 2e-5 and rel(ls.grad.numpy(), g[tag + "_dls"]) < 2e-5
+    assert rel(theta.grad.numpy(), g[tag + ("_dRs" if tag == "rs" else "_dtheta")]) < 2e-5
+    if del_v is not None:
+        assert rel(del_v.grad.numpy()[:, vsel], g[tag + "_ddel_v"]) < 2e-5
+    if v_tmpl is not None:
+        assert rel(v_tmpl.grad.numpy()[vsel], g[tag + "_dv_template"]) < 2e-5
