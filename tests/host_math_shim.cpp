@@ -76,6 +76,32 @@ void hm_raster(const float* v, int V, const int* faces, int F, int S, const floa
   }
 }
 
+// face_pixel_candidate (the forward sweep's / selection's form) against face_pixel_eval (the backward's form) on every
+// (face, pixel) pair of a mesh: counts pairs on which the candidate decision or the bits of the signed distance differ
+int hm_candidate_mismatches(const float* v, const int* faces, int F, int S, long long* pairs_out) {
+  const float inv_s = 1.0f / (float)S;
+  int bad = 0;
+  long long pairs = 0;
+  for (int f = 0; f < F; ++f) {
+    const float* a = v + 3 * faces[3 * f];
+    const float* b = v + 3 * faces[3 * f + 1];
+    const float* c = v + 3 * faces[3 * f + 2];
+    FaceRec r;
+    if (!make_face_rec(a[0], a[1], a[2], b[0], b[1], b[2], c[0], c[1], c[2], r)) continue;
+    for (int row = 0; row < S; ++row)
+      for (int col = 0; col < S; ++col) {
+        const float px = pix_to_ndc(col, inv_s), py = pix_to_ndc(row, inv_s);
+        PixEval e;
+        float d2;
+        const bool k1 = face_pixel_eval(r, px, py, e), k2 = face_pixel_candidate(r, px, py, d2);
+        ++pairs;
+        if (k1 != k2 || (k1 && (e.d != d2 || e.pz != face_pixel_depth(r, px, py)))) ++bad;
+      }
+  }
+  *pairs_out = pairs;
+  return bad;
+}
+
 // global_rigid_kernel on the host: one call of global_rigid_frame per frame
 void hm_global_rigid(int n, const float* Rs, const float* Js, const int* parents, const float* logscale, float* newJ, float* A) {
   for (int i = 0; i < n; ++i)

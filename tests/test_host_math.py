@@ -121,3 +121,24 @@ def test_global_rigid_transformation_host_against_reference_golden(shim, golden,
     assert np.linalg.norm(newJ - want_J) / np.linalg.norm(want_J) < 2e-6
     assert np.linalg.norm(A - want_A) / np.linalg.norm(want_A) < 2e-6
     assert (A[:, :, 3, :] == np.array([0, 0, 0, 1.0], np.float32)).all()
+
+
+@pytest.mark.parametrize("S,z", [(48, 0.0), (100, 1.45)])
+def test_candidate_form_agrees_bitwise_with_the_full_evaluation(shim, synth_model, S, z):
+    """the forward sweep and the selection decide candidates with face_pixel_candidate, the backward with
+    face_pixel_eval: on every (face, pixel) pair of the posed mesh the decision and the bits of the signed distance and the
+    depth must be identical (the K-nearest bookkeeping relies on all kernels seeing the same candidates)"""
+    md = synth_model
+    om = so.OracleModel(md)
+    rs = np.random.RandomState(1)
+    theta = np.concatenate([model_io.initial_global_rotation()[None, None], 0.2 * rs.randn(1, 34, 3)], 1)
+    with torch.no_grad():
+        v, _, _, _ = so.smal_forward(om, torch.zeros(1, 20).double(), torch.from_numpy(theta).double(), torch.zeros(1, 6).double())
+        v = (v + torch.tensor([0.02, -0.01, z]).double()).float()
+    xn, yn, zv = so.world_to_ndc(v[0])
+    vn = np.ascontiguousarray(torch.stack([xn, yn, zv], 1).numpy(), np.float32)
+    faces = np.ascontiguousarray(md.faces, np.int32)
+    pairs = C.c_longlong(0)
+    shim.hm_candidate_mismatches.restype = C.c_int
+    bad = shim.hm_candidate_mismatches(_p(vn), _p(faces), faces.shape[0], S, C.byref(pairs))
+    assert pairs.value > 1e7 and bad == 0, (bad, pairs.value)
