@@ -132,10 +132,15 @@ int smalfit_rodrigues_backward(void* stream, int count, const float* theta, cons
 
 /* replaces: batch_global_rigid_transformation(Rs, Js, parent, betas_logscale=...)   reference smal_model/batch_lbs.py:75-170
  * Rs (count,35,3,3)  Js (count,35,3)  parents: host int[35] with parents[i] < i (parents[0] ignored)
- * logscale (count,6) or NULL -> new_J (count,35,3), A (count,35,4,4).  Forward only: inside the fitting path the chain
- * and its adjoint are part of smalfit_lbs_forward / _backward and smalfit_fit_eval. */
+ * logscale (count,6) or NULL -> new_J (count,35,3), A (count,35,4,4).  (Inside the fitting path the chain and its
+ * adjoint are part of smalfit_lbs_forward / _backward and smalfit_fit_eval.) */
 int smalfit_global_rigid_transformation(void* stream, int count, const float* Rs, const float* Js,
                                         const int* parents /*host*/, const float* logscale, float* new_J, float* A);
+/* its adjoint (autograd of the reference's function): d_new_J (count,35,3), d_A (count,35,4,4) -> dRs (count,35,3,3),
+ * dJs (count,35,3), dlogscale (count,6) (ignored when logscale is NULL); scratch: count * 840 floats of device memory */
+int smalfit_global_rigid_transformation_backward(void* stream, int count, const float* Rs, const float* Js,
+                                                 const int* parents /*host*/, const float* logscale, const float* d_new_J,
+                                                 const float* d_A, float* scratch, float* dRs, float* dJs, float* dlogscale);
 
 /* ---- Renderer.forward ---------------------------------------------------------------------------
  * replaces: Renderer.forward(vertices, points, faces)        reference smal_fitter/p3d_renderer.py:61-74

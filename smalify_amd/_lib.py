@@ -95,6 +95,7 @@ SIGNATURES = {
     "smalfit_rodrigues": (_I, [_VP, _I, _VP, _VP]),
     "smalfit_rodrigues_backward": (_I, [_VP, _I, _VP, _VP, _VP]),
     "smalfit_global_rigid_transformation": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "smalfit_global_rigid_transformation_backward": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "smalfit_render_forward": (_I, [_VP, _VP, _I, _VP, _VP, _I, _VP, _VP]),
     "smalfit_render_color": (_I, [_VP, _VP, _I, _VP, _VP, _VP]),
     "smalfit_render_backward": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP]),

@@ -159,6 +159,94 @@ SMALFIT_HD void global_rigid_frame(const float* Rs, const float* Js, const int* 
   }
 }
 
+// Adjoint of global_rigid_frame: dnewJ [35][3] and dA [35][16] (4x4 row-major; the constant bottom rows are ignored)
+// -> dRs [35][9], dJs [35][3], dlogscale [6] (written only when logscale != null).  The chain is re-run forward into G
+// (caller scratch, [35][12] = rows 0..2 of each 4x4), then walked in reverse joint order.
+SMALFIT_HD void global_rigid_frame_bwd(const float* Rs, const float* Js, const int* parents, const float* logscale,
+                                       const float* dnewJ, const float* dA, float* G /*[35][12] scratch*/,
+                                       float* dG /*[35][12] scratch*/, float* dRs, float* dJs, float* dlogscale) {
+  float es[6], ies[6], des[6];
+  for (int k = 0; k < 6; ++k) {
+    es[k] = logscale != nullptr ? expf(logscale[k]) : 1.0f;
+    ies[k] = 1.0f / es[k];
+    des[k] = 0.f;
+  }
+  auto sc = [&](int j, int a) { const int si = limb_scale_index(j, a); return si >= 0 ? es[si] : 1.0f; };
+  auto isc = [&](int j, int a) { const int si = limb_scale_index(j, a); return si >= 0 ? ies[si] : 1.0f; };
+  // forward chain (the same operations as global_rigid_frame)
+  for (int i = 0; i < kJoints; ++i) {
+    float* g = G + 12 * i;
+    if (i == 0) {
+      for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) g[r * 4 + c] = Rs[r * 3 + c]; g[r * 4 + 3] = Js[r]; }
+    } else {
+      const int p = parents[i];
+      const float* gp = G + 12 * p;
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) {
+          float acc = 0.f;
+          for (int q = 0; q < 3; ++q) acc = fmaf(gp[r * 4 + q], Rs[9 * i + q * 3 + c] * sc(i, c) * isc(p, q), acc);
+          g[r * 4 + c] = acc;
+        }
+        float acc = gp[r * 4 + 3];
+        for (int q = 0; q < 3; ++q) acc = fmaf(gp[r * 4 + q], Js[3 * i + q] - Js[3 * p + q], acc);
+        g[r * 4 + 3] = acc;
+      }
+    }
+  }
+  // A_i = [G.R | G.t - G.R J_i], newJ_i = G.t
+  for (int i = 0; i < kJoints; ++i) {
+    const float* da = dA + 16 * i;
+    const float* g = G + 12 * i;
+    float* dg = dG + 12 * i;
+    for (int r = 0; r < 3; ++r) {
+      for (int q = 0; q < 3; ++q) dg[r * 4 + q] = da[r * 4 + q] - da[r * 4 + 3] * Js[3 * i + q];
+      dg[r * 4 + 3] = da[r * 4 + 3] + dnewJ[3 * i + r];
+    }
+    for (int q = 0; q < 3; ++q) {
+      float acc = 0.f;
+      for (int r = 0; r < 3; ++r) acc = fmaf(-g[r * 4 + q], da[r * 4 + 3], acc);
+      dJs[3 * i + q] = acc;
+    }
+  }
+  for (int i = kJoints - 1; i >= 1; --i) {
+    const int p = parents[i];
+    const float* gp = G + 12 * p;
+    const float* dg = dG + 12 * i;
+    float* dgp = dG + 12 * p;
+    // dR' = G_p.R^T dG_i.R ;  dj = G_p.R^T dG_i.t
+    float dRp[9], dj[3];
+    for (int q = 0; q < 3; ++q) {
+      for (int c = 0; c < 3; ++c) dRp[q * 3 + c] = gp[0 * 4 + q] * dg[0 * 4 + c] + gp[1 * 4 + q] * dg[1 * 4 + c] + gp[2 * 4 + q] * dg[2 * 4 + c];
+      dj[q] = gp[0 * 4 + q] * dg[3] + gp[1 * 4 + q] * dg[7] + gp[2 * 4 + q] * dg[11];
+    }
+    for (int r = 0; r < 3; ++r) {
+      for (int q = 0; q < 3; ++q) {
+        // dG_p.R[r][q] += sum_c dG_i.R[r][c] R'[q][c] + dG_i.t[r] (J_i - J_p)[q]
+        float acc = dg[r * 4 + 3] * (Js[3 * i + q] - Js[3 * p + q]);
+        for (int c = 0; c < 3; ++c) acc = fmaf(dg[r * 4 + c], Rs[9 * i + q * 3 + c] * sc(i, c) * isc(p, q), acc);
+        dgp[r * 4 + q] += acc;
+      }
+      dgp[r * 4 + 3] += dg[r * 4 + 3];
+    }
+    for (int q = 0; q < 3; ++q) { dJs[3 * i + q] += dj[q]; dJs[3 * p + q] -= dj[q]; }
+    for (int q = 0; q < 3; ++q)
+      for (int c = 0; c < 3; ++c) {
+        const float rp = Rs[9 * i + q * 3 + c];
+        dRs[9 * i + q * 3 + c] = dRp[q * 3 + c] * sc(i, c) * isc(p, q);
+        const int si = limb_scale_index(i, c), sp = limb_scale_index(p, q);
+        // R'[q][c] = R[q][c] s_i[c] / s_p[q]:  d/ds_i[c] = R / s_p[q],  d/ds_p[q] = -R' / s_p[q]
+        if (si >= 0) des[si] += dRp[q * 3 + c] * rp * isc(p, q);
+        if (sp >= 0) des[sp] -= dRp[q * 3 + c] * rp * sc(i, c) * isc(p, q) * isc(p, q);
+      }
+  }
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) dRs[r * 3 + c] = dG[r * 4 + c];
+    dJs[r] += dG[r * 4 + 3];
+  }
+  if (logscale != nullptr && dlogscale != nullptr)
+    for (int k = 0; k < 6; ++k) dlogscale[k] = des[k] * es[k];
+}
+
 // ------------------------------------------------------------------------------------------------
 // camera: world -> (x_ndc, y_ndc, z_view) and its adjoint
 // ------------------------------------------------------------------------------------------------

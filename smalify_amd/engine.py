@@ -353,7 +353,7 @@ def rodrigues_backward(theta, dR):
 
 def global_rigid_transformation(Rs, Js, parents, logscale=None):
     """Rs (N,35,3,3), Js (N,35,3), parents (35,) host ints, logscale (N,6) or None -> new_J (N,35,3), A (N,35,4,4)
-    (reference batch_lbs.py:75-170; forward only)"""
+    (reference batch_lbs.py:75-170; adjoint: global_rigid_transformation_backward)"""
     lib = _lib.load()
     N = int(Rs.shape[0])
     if tuple(Rs.shape) != (N, 35, 3, 3) or tuple(Js.shape) != (N, 35, 3):
@@ -368,6 +368,20 @@ def global_rigid_transformation(Rs, Js, parents, logscale=None):
     check(lib.smalfit_global_rigid_transformation(_stream(), N, _ptr(Rs), _ptr(Js), par.ctypes.data, _ptr(logscale),
                                                   _ptr(new_J), _ptr(A)), "smalfit_global_rigid_transformation")
     return new_J, A
+
+
+def global_rigid_transformation_backward(Rs, Js, parents, logscale, d_new_J, d_A):
+    """adjoint of global_rigid_transformation -> (dRs (N,35,3,3), dJs (N,35,3), dlogscale (N,6) or None)"""
+    lib = _lib.load()
+    N = int(Rs.shape[0])
+    par = _host(parents, np.int32).reshape(-1)
+    dRs, dJs = torch.empty_like(Rs), torch.empty_like(Js)
+    dls = torch.empty_like(logscale) if logscale is not None else None
+    scratch = torch.empty(N * 840, device=Rs.device)
+    check(lib.smalfit_global_rigid_transformation_backward(_stream(), N, _ptr(Rs), _ptr(Js), par.ctypes.data, _ptr(logscale),
+                                                           _ptr(d_new_J), _ptr(d_A), _ptr(scratch), _ptr(dRs), _ptr(dJs),
+                                                           _ptr(dls)), "smalfit_global_rigid_transformation_backward")
+    return dRs, dJs, dls
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, t, beta1=0.5, beta2=0.999, eps=1e-8):

@@ -1,8 +1,8 @@
 """Drop-in for reference smal_model/batch_lbs.py (the functions the fitting path uses).
 
 batch_rodrigues runs the HIP kernel (smalfit_rodrigues) with an analytic adjoint.
-batch_global_rigid_transformation runs smalfit_global_rigid_transformation (forward only: inside the fitting path the
-chain and its adjoint are fused into SMAL.__call__, lbs_head_kernel / chain_bwd_kernel)."""
+batch_global_rigid_transformation runs smalfit_global_rigid_transformation / _backward (inside the fitting path the chain
+and its adjoint are fused into SMAL.__call__: lbs_head_kernel / chain_bwd_kernel)."""
 from __future__ import annotations
 
 import numpy as np
@@ -33,14 +33,20 @@ class _GlobalRigid(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Rs, Js, logscale, parent):
         ls = None if logscale is None else logscale.contiguous().float()
-        new_J, A = eng.global_rigid_transformation(Rs.contiguous().float(), Js.contiguous().float(), parent, ls)
+        Rs, Js = Rs.contiguous().float(), Js.contiguous().float()
+        new_J, A = eng.global_rigid_transformation(Rs, Js, parent, ls)
+        ctx.parent, ctx.has_ls = parent, ls is not None
+        ctx.save_for_backward(Rs, Js, ls if ls is not None else Rs.new_zeros(1))
         return new_J, A
 
     @staticmethod
     def backward(ctx, d_new_J, d_A):
-        raise NotImplementedError(
-            "batch_global_rigid_transformation is forward-only here; gradients of the kinematic chain flow through "
-            "SMAL.__call__ (smalfit_lbs_backward), which is how the reference's fitters reach it")
+        Rs, Js, ls = ctx.saved_tensors
+        ls = ls if ctx.has_ls else None
+        dn = torch.zeros_like(Js) if d_new_J is None else d_new_J.contiguous().float()
+        dA = Rs.new_zeros(Rs.shape[0], 35, 4, 4) if d_A is None else d_A.contiguous().float()
+        dRs, dJs, dls = eng.global_rigid_transformation_backward(Rs, Js, ctx.parent, ls, dn, dA)
+        return dRs, dJs, dls, None
 
 
 def batch_global_rigid_transformation(Rs, Js, parent, rotate_base=False, betas_logscale=None, opts=None):

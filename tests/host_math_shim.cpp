@@ -109,6 +109,15 @@ void hm_global_rigid(int n, const float* Rs, const float* Js, const int* parents
                        newJ + (size_t)i * 105, A + (size_t)i * 560);
 }
 
+void hm_global_rigid_bwd(int n, const float* Rs, const float* Js, const int* parents, const float* logscale, const float* dnewJ,
+                         const float* dA, float* dRs, float* dJs, float* dls) {
+  std::vector<float> scratch(840);
+  for (int i = 0; i < n; ++i)
+    global_rigid_frame_bwd(Rs + (size_t)i * 315, Js + (size_t)i * 105, parents, logscale ? logscale + (size_t)i * 6 : nullptr,
+                           dnewJ + (size_t)i * 105, dA + (size_t)i * 560, scratch.data(), scratch.data() + 420,
+                           dRs + (size_t)i * 315, dJs + (size_t)i * 105, logscale ? dls + (size_t)i * 6 : nullptr);
+}
+
 void hm_camera(int n, const float* p, const float* g2, float* ndc, float* g3) {
   for (int i = 0; i < n; ++i) {
     world_to_ndc(p[3 * i], p[3 * i + 1], p[3 * i + 2], ndc[3 * i], ndc[3 * i + 1], ndc[3 * i + 2]);

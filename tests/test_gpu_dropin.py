@@ -88,6 +88,24 @@ def test_smal_call_options_match_the_reference(md, tag):
         assert rel(kw["v_template"].grad[vsel].cpu(), g[tag + "_dv_template"]) < 2e-4
 
 
+@pytest.mark.parametrize("scaled", [False, True])
+def test_global_rigid_transformation_gradients_match_the_reference(scaled):
+    """drop-in batch_global_rigid_transformation: values and autograd against the reference's own function and autograd
+    (tests/golden/reference_golden_smal_options.npz)"""
+    from smalify_amd.smal_model.batch_lbs import batch_global_rigid_transformation
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_golden_smal_options.npz")))
+    tag = "chain_scale" if scaled else "chain_noscale"
+    t = lambda a: torch.tensor(np.asarray(a), device="cuda", requires_grad=True)  # noqa: E731
+    R, J = t(g["chain_Rs"]), t(g["chain_Js"])
+    L = t(g["chain_ls"]) if scaled else None
+    nj, A = batch_global_rigid_transformation(R, J, g["chain_parents"], betas_logscale=L)
+    assert rel(nj.detach().cpu(), g[tag + "_newJ"]) < 1e-5 and rel(A.detach().cpu(), g[tag + "_A"]) < 1e-5
+    ((nj * torch.from_numpy(g["chain_wn"]).cuda()).sum() + (A * torch.from_numpy(g["chain_wa"]).cuda()).sum()).backward()
+    assert rel(R.grad.cpu(), g[tag + "_dRs"]) < 2e-4 and rel(J.grad.cpu(), g[tag + "_dJs"]) < 2e-4
+    if scaled:
+        assert rel(L.grad.cpu(), g[tag + "_dls"]) < 2e-4
+
+
 def test_batch_rodrigues_matches_reference_golden(golden):
     from smalify_amd.smal_model.batch_lbs import batch_rodrigues
     R = batch_rodrigues(torch.from_numpy(golden["g1_theta"]).cuda())

@@ -142,3 +142,30 @@ def test_candidate_form_agrees_bitwise_with_the_full_evaluation(shim, synth_mode
     shim.hm_candidate_mismatches.restype = C.c_int
     bad = shim.hm_candidate_mismatches(_p(vn), _p(faces), faces.shape[0], S, C.byref(pairs))
     assert pairs.value > 1e7 and bad == 0, (bad, pairs.value)
+
+
+@pytest.mark.parametrize("scaled", [False, True])
+def test_global_rigid_transformation_adjoint_host(shim, synth_model, scaled):
+    """global_rigid_frame_bwd (the free-standing adjoint of batch_global_rigid_transformation, batch_lbs.py:75-170) against
+    the oracle's autograd through its restatement of the chain"""
+    rs = np.random.RandomState(5)
+    n = 3
+    th = (0.5 * rs.randn(n * 35, 3)).astype(np.float32)
+    Rs = so.rodrigues(torch.from_numpy(th).double()).reshape(n, 35, 3, 3).float().numpy().copy()
+    Js = (0.3 * rs.randn(n, 35, 3)).astype(np.float32)
+    ls = (0.3 * rs.randn(n, 6)).astype(np.float32) if scaled else None
+    dnewJ = rs.randn(n, 35, 3).astype(np.float32)
+    dA = rs.randn(n, 35, 4, 4).astype(np.float32)
+    parents = np.ascontiguousarray(synth_model.parents, np.int32)
+    dRs, dJs, dls = np.zeros_like(Rs), np.zeros_like(Js), np.zeros((n, 6), np.float32)
+    shim.hm_global_rigid_bwd(n, _p(Rs), _p(Js), _p(parents), _p(ls) if scaled else None, _p(dnewJ), _p(dA), _p(dRs), _p(dJs), _p(dls))
+    R64 = torch.from_numpy(Rs).double().requires_grad_(True)
+    J64 = torch.from_numpy(Js).double().requires_grad_(True)
+    l64 = torch.from_numpy(ls).double().requires_grad_(True) if scaled else None
+    g_t, g_r, a_t = so.kinematic_chain(R64, J64, [int(p) for p in parents], l64)
+    dA64 = torch.from_numpy(dA).double()
+    ((g_t * torch.from_numpy(dnewJ).double()).sum() + (g_r * dA64[:, :, :3, :3]).sum() + (a_t * dA64[:, :, :3, 3]).sum()).backward()
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))  # noqa: E731
+    assert rel(dRs, R64.grad.numpy()) < 5e-6 and rel(dJs, J64.grad.numpy()) < 5e-6
+    if scaled:
+        assert rel(dls, l64.grad.numpy()) < 5e-6

@@ -229,3 +229,24 @@ def test_smal_call_options_against_the_reference(synth_model, tag):
         assert rel(del_v.grad.numpy()[:, vsel], g[tag + "_ddel_v"]) < 2e-5
     if v_tmpl is not None:
         assert rel(v_tmpl.grad.numpy()[vsel], g[tag + "_dv_template"]) < 2e-5
+
+
+@pytest.mark.parametrize("scaled", [False, True])
+def test_kinematic_chain_autograd_against_the_reference(scaled):
+    """values and gradients of the reference's batch_global_rigid_transformation (its own autograd) vs the oracle's chain"""
+    import torch
+    from oracle import smal_oracle as so
+    g = _smal_options_golden()
+    tag = "chain_scale" if scaled else "chain_noscale"
+    R = torch.from_numpy(g["chain_Rs"]).double().requires_grad_(True)
+    J = torch.from_numpy(g["chain_Js"]).double().requires_grad_(True)
+    L = torch.from_numpy(g["chain_ls"]).double().requires_grad_(True) if scaled else None
+    g_t, g_r, a_t = so.kinematic_chain(R, J, [int(p) for p in g["chain_parents"]], L)
+    wa = torch.from_numpy(g["chain_wa"]).double()
+    ((g_t * torch.from_numpy(g["chain_wn"]).double()).sum() + (g_r * wa[:, :, :3, :3]).sum() + (a_t * wa[:, :, :3, 3]).sum()).backward()
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / np.linalg.norm(b))  # noqa: E731
+    assert rel(g_t.detach().numpy(), g[tag + "_newJ"]) < 2e-6
+    assert rel(g_r.detach().numpy(), g[tag + "_A"][:, :, :3, :3]) < 2e-6 and rel(a_t.detach().numpy(), g[tag + "_A"][:, :, :3, 3]) < 2e-6
+    assert rel(R.grad.numpy(), g[tag + "_dRs"]) < 2e-5 and rel(J.grad.numpy(), g[tag + "_dJs"]) < 2e-5
+    if scaled:
+        assert rel(L.grad.numpy(), g[tag + "_dls"]) < 2e-5
