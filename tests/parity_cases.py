@@ -5,6 +5,8 @@ Oracle = oracle/smal_oracle.py in float64 (test infrastructure).  HIP = smalify_
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -27,11 +29,20 @@ def dev(x):
 _CACHE = {}
 
 
+def get_oracle_model(dense=False):
+    """(model description, oracle model): CPU only"""
+    key = ("oracle_model", dense)
+    if key not in _CACHE:
+        md = synthetic.synthetic_model(seed=0, shape_family_id=1, dense_weights=dense)
+        _CACHE[key] = (md, so.OracleModel(md))
+    return _CACHE[key]
+
+
 def get_model(dense=False):
     key = ("model", dense)
     if key not in _CACHE:
-        md = synthetic.synthetic_model(seed=0, shape_family_id=1, dense_weights=dense)
-        _CACHE[key] = (md, so.OracleModel(md), eng.DeviceModel(md))
+        md, om = get_oracle_model(dense)
+        _CACHE[key] = (md, om, eng.DeviceModel(md))
     return _CACHE[key]
 
 
@@ -142,10 +153,11 @@ def case_render(M=2, S=64, z=1.45, seed=11, shrink=1.0):
     return out
 
 
-def make_problem(M, S, window, seed=21, z=1.45, with_sil=True):
-    """Synthetic fitting problem: targets from a ground-truth pose, evaluation at a perturbed pose."""
-    md, om, _ = get_model()
-    e, pp, sp = get_engine(max(M, 8), S)
+def make_problem_cpu(M, S, window, seed=21, z=1.45, with_sil=True):
+    """Synthetic fitting problem: targets from a ground-truth pose, evaluation at a perturbed pose (oracle side only)."""
+    md, om = get_oracle_model()
+    pp = synthetic.synthetic_pose_prior()
+    sp = synthetic.synthetic_shape_prior()
     gt = random_pose(M, seed, z=z)
     cur = random_pose(M, seed, z=z)
     rs = np.random.RandomState(seed + 7)
@@ -167,7 +179,14 @@ def make_problem(M, S, window, seed=21, z=1.45, with_sil=True):
     vis = (rs.rand(M, 25) < 0.85).astype(np.float32)
     vis[:, [2, 5, 8]] = 1.0
     prob = so.FitProblem(om, S, tj, vis, tsil, pp[0], pp[1], pp[2], sp[0], sp[1], window, use_unity_prior=True)
-    return e, prob, cur, dict(tj=tj.astype(np.float32), vis=vis, tsil=tsil.astype(np.float32))
+    return prob, cur, dict(tj=tj.astype(np.float32), vis=vis, tsil=tsil.astype(np.float32))
+
+
+def make_problem(M, S, window, seed=21, z=1.45, with_sil=True):
+    """make_problem_cpu + the device engine holding the same priors"""
+    e, _, _ = get_engine(max(M, 8), S)
+    prob, cur, tg = make_problem_cpu(M, S, window, seed, z, with_sil)
+    return e, prob, cur, tg
 
 
 def case_fit(M=4, S=64, window=2, stage=2, seed=21, trainable=None):
@@ -386,17 +405,17 @@ def case_u8_targets(M=8, S=128, window=4, iters=6, seed=29):
             "losses_identical": bool(np.array_equal(res["f32"][1], res["u8"][1])), "status": e.status()}
 
 
-def case_full_schedule(M=4, S=64, window=2, iters_scale=0.1, seed=21):
-    """All four stages of the reference schedule (config.OPT_WEIGHTS: weights, learning rates, stage-0 freeze and torso
-    keypoints, fresh Adam per stage), iteration counts scaled by `iters_scale`: FusedFitter on the GPU (one library call
-    per stage) against the oracle's loss + autograd + Adam on the CPU from the same start.  Returns the final per-term
-    losses of both, their relative differences, and the end-of-run relative L2 difference of every parameter tensor
-    (SURVEY.md section 7, checks (iii) and (iv))."""
-    from smalify_amd import fitter as fit
+FULL_SCHEDULE_FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_full_schedule.npz")
+
+
+def full_schedule_iterations(iters_scale):
+    return [max(1, int(round(int(w[7]) * iters_scale))) for w in np.array(cfg.OPT_WEIGHTS).T]
+
+
+def full_schedule_oracle(prob, cur, sched, trace=None):
+    """the oracle's stage loop (optimize_to_joints.py:90-137) in float64 from the start `cur`: final per-term sums and
+    parameters.  `trace`, if a list, receives the total of every iteration."""
     W = np.array(cfg.OPT_WEIGHTS).T
-    e, prob, cur, tg = make_problem(M, S, window, seed)
-    sched = [max(1, int(round(int(w[7]) * iters_scale))) for w in W]
-    # oracle loop (optimize_to_joints.py:90-137)
     params = {k: torch.from_numpy(v).double() for k, v in cur.items()}
     sums_o = {}
     for stage, w in enumerate(W):
@@ -406,7 +425,53 @@ def case_full_schedule(M=4, S=64, window=2, iters_scale=0.1, seed=21):
         opt = so.Adam(so.PARAM_ORDER, lr=lr)
         for _ in range(sched[stage]):
             total, sums_o, grads = so.loss_and_grads(prob, params, weights, w_temp, names, visibility=vis)
+            if trace is not None:
+                trace.append(float(total))
             opt.step(params, grads)
+    return {"sums": {k: float(v) for k, v in sums_o.items()}, "params": {k: v.numpy() for k, v in params.items()}}
+
+
+def problem_fingerprint(cur, tg):
+    """sha256 over the start parameters and targets of a problem: a cached oracle result belongs to exactly these inputs"""
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(cur):
+        h.update(np.ascontiguousarray(cur[k]).tobytes())
+    for k in sorted(tg):
+        h.update(np.ascontiguousarray(tg[k]).tobytes())
+    return h.hexdigest()
+
+
+def load_full_schedule_fixture(M, S, window, iters_scale, seed, cur, tg):
+    """tests/golden/oracle_full_schedule.npz (written by tests/golden/make_oracle_full_schedule.py) holds the ORACLE's
+    end state for one configuration -- minutes of float64 CPU work that the GPU box would otherwise repeat in every run.
+    Used only when the configuration and the fingerprint of the problem's inputs match; anything else runs the oracle."""
+    if not os.path.exists(FULL_SCHEDULE_FIXTURE):
+        return None
+    z = np.load(FULL_SCHEDULE_FIXTURE, allow_pickle=False)
+    key = "M%d_S%d_w%d_scale%g_seed%d" % (M, S, window, iters_scale, seed)
+    if str(z["config"]) != key or str(z["fingerprint"]) != problem_fingerprint(cur, tg):
+        return None
+    return {"sums": {k[4:]: float(z[k]) for k in z.files if k.startswith("sum_")},
+            "params": {k[6:]: z[k] for k in z.files if k.startswith("param_")}}
+
+
+def case_full_schedule(M=4, S=64, window=2, iters_scale=0.1, seed=21):
+    """All four stages of the reference schedule (config.OPT_WEIGHTS: weights, learning rates, stage-0 freeze and torso
+    keypoints, fresh Adam per stage), iteration counts scaled by `iters_scale`: FusedFitter on the GPU (one library call
+    per stage) against the oracle's loss + autograd + Adam on the CPU from the same start.  Returns the final per-term
+    losses of both, their relative differences, and the end-of-run relative L2 difference of every parameter tensor
+    (SURVEY.md section 7, checks (iii) and (iv))."""
+    from smalify_amd import fitter as fit
+    W = np.array(cfg.OPT_WEIGHTS).T
+    e, prob, cur, tg = make_problem(M, S, window, seed)
+    sched = full_schedule_iterations(iters_scale)
+    orc = load_full_schedule_fixture(M, S, window, iters_scale, seed, cur, tg)
+    oracle_source = "fixture"
+    if orc is None:
+        orc = full_schedule_oracle(prob, cur, sched)
+        oracle_source = "live"
+    sums_o, params = orc["sums"], {k: torch.from_numpy(v) for k, v in orc["params"].items()}
     # device loop
     f = fit.FusedFitter(e, tg["tj"], tg["vis"], tg["tsil"], window, True, cur["betas"], cur["log_beta_scales"])
     for k in ("global_rotation", "joint_rotations", "trans"):
@@ -415,7 +480,7 @@ def case_full_schedule(M=4, S=64, window=2, iters_scale=0.1, seed=21):
         f.begin_stage(stage)
         f.run_iterations(w[:6].copy(), float(w[6]), float(w[8]), stage, sched[stage])
     l = f.losses.cpu().numpy().astype(np.float64)
-    out = {"schedule": sched, "status": e.status(), "final_total_oracle": float(sum(sums_o.values())), "final_total_hip": float(l.sum())}
+    out = {"schedule": sched, "oracle_source": oracle_source, "status": e.status(), "final_total_oracle": float(sum(sums_o.values())), "final_total_hip": float(l.sum())}
     out["final_total_rel"] = abs(out["final_total_hip"] - out["final_total_oracle"]) / abs(out["final_total_oracle"])
     for i, nme in enumerate(eng.LOSS_NAMES):
         ref = float(sums_o.get(nme, 0.0))

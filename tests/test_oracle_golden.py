@@ -5,6 +5,8 @@ Tolerances: the reference computes in float32, the oracle in float64, so differe
 reference's own round-off: 2e-5 relative on values, 2e-4 relative (norm-wise) on gradients that pass
 through the 34-step chain and 3889-vertex reductions.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -250,3 +252,25 @@ def test_kinematic_chain_autograd_against_the_reference(scaled):
     assert rel(R.grad.numpy(), g[tag + "_dRs"]) < 2e-5 and rel(J.grad.numpy(), g[tag + "_dJs"]) < 2e-5
     if scaled:
         assert rel(L.grad.numpy(), g[tag + "_dls"]) < 2e-5
+
+
+def test_full_schedule_fixture_is_current():
+    """tests/golden/oracle_full_schedule.npz caches the oracle's end state of the scaled four-stage fit (minutes of float64
+    CPU work) for tests/test_gpu_parity.py::test_full_schedule.  It must belong to the problem the test builds today
+    (same inputs, bit for bit) and to today's oracle: the head of the loop is replayed here and compared with the stored
+    trace of totals."""
+    from tests import parity_cases as pc
+    from tests.golden import make_oracle_full_schedule as gen
+    assert os.path.exists(pc.FULL_SCHEDULE_FIXTURE), "run tests/golden/make_oracle_full_schedule.py"
+    z = np.load(pc.FULL_SCHEDULE_FIXTURE, allow_pickle=False)
+    prob, cur, tg = pc.make_problem_cpu(gen.M, gen.S, gen.WINDOW, gen.SEED)
+    assert pc.load_full_schedule_fixture(gen.M, gen.S, gen.WINDOW, gen.SCALE, gen.SEED, cur, tg) is not None, \
+        "fixture belongs to other inputs: regenerate it"
+    sched = pc.full_schedule_iterations(gen.SCALE)
+    assert list(z["schedule"]) == sched and len(z["trace"]) == sum(sched)
+    head = [sched[0], 2, 0, 0]               # all of stage 0 (keypoints only) and two silhouette iterations of stage 1
+    trace = []
+    pc.full_schedule_oracle(prob, cur, head, trace)
+    np.testing.assert_allclose(trace, z["trace"][:len(trace)], rtol=1e-9)
+    # the stored per-term sums are those of the last evaluation
+    np.testing.assert_allclose(sum(float(z[k]) for k in z.files if k.startswith("sum_")), z["trace"][-1], rtol=1e-9)
