@@ -3,12 +3,20 @@ optimiser step, under different ways of carrying the bounds from one iteration t
 
 The HIP rasteriser keeps, per pixel with more than K = 100 candidates, two depths lo < z_K <= hi around the depth of the
 K-th nearest candidate (smalify_amd/csrc/kernels_raster.inc, raster_select_kernel / raster_band_kernel).  The next
-evaluation is exact without a new selection iff  #{z <= lo} <= K <= #{z <= hi}  and  #{lo < z <= hi} <= 64.  This
-script runs the oracle's fit on a few frames of the benchmark problem, records every candidate depth per pixel per
-iteration, and replays that rule with the bounds (a) left where they were, (b) shifted by the mean change of the
-vertices' depths, (c) shifted by an affine function of the pixel fitted to the vertices' depth changes.
+evaluation is exact without a new selection iff  #{z <= lo} <= K <= #{z <= hi}  and  #{lo < z <= hi} <= band capacity.
+This script runs the oracle's fit on a few frames of the benchmark problem with bench.py's scaled schedule, records
+every candidate depth per pixel per iteration, and replays that rule with the bounds
+  none         left where they were (what the kernels do; reproduces the hit rates measured on the GPU),
+  affine_dz    shifted by an affine function of the pixel fitted to the vertices' depth changes,
+  warp_mean    looked up at the pixel the mesh's mean screen motion came from (+ affine_dz),
+  warp_affine  the same with an affine screen motion fitted to the vertices,
+  anchor_k     tied to the depth plane of the face that was the K-th nearest at the last selection,
+  anchor_flat  tied to the flattest face within 12 ranks of the K-th.
+Findings are summarised in DESIGN.md section 5.
 
-usage: python tests/band_policy_sim.py [frames=2] [steps=20]
+usage: [SIM_VARIANTS=none,warp_affine] [SIM_FILL=60 SIM_CAP=64 SIM_HALF=8 SIM_TRIES=6] python tests/band_policy_sim.py [frames=2] [steps=20]
+       (SIM_FILL: most entries a new band may hold, SIM_CAP: band list capacity, SIM_HALF: initial half-width in mean
+       depth gaps of the K nearest, SIM_TRIES: halvings tried)
 """
 import os
 import sys
@@ -177,7 +185,7 @@ def main():
     FILL = int(os.environ.get('SIM_FILL', '60'))
     state = [None] * nf                 # per frame: dict(lo, hi) per variant
     prev = [None] * nf
-    variants = ("none", "warp_affine")
+    variants = tuple(os.environ.get("SIM_VARIANTS", "none,warp_affine").split(","))
     anchor = [None] * nf
     for label, verts in traj:
         row = {}
