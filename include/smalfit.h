@@ -30,6 +30,12 @@ typedef struct smalfit_engine smalfit_engine;
 
 #define SMALFIT_STATUS_BIN_OVERFLOW 1 /* reserved */
 
+/* ABI version of this header.  smalfit_version() returns the version the library was built from; a caller compares the
+ * two once at load time (smalify_amd/_lib.py does) -- the argument structs below are passed by pointer and grow at the
+ * tail from version to version.  History: 1 = round 1; 2 = 9 loss terms (losses must hold SMALFIT_NUM_LOSS_TERMS floats),
+ * smalfit_fit_args gained target_sil_u8 / w_limit; 3 = smalfit_fit_args.struct_size (first field), frame_offset,
+ * total_frames; smalfit_engine_clear_joint_limits, smalfit_shard_local_step. */
+#define SMALFIT_ABI_VERSION 3
 int smalfit_version(void);
 const char* smalfit_last_error(void);
 
@@ -87,6 +93,8 @@ int smalfit_engine_set_pose_prior(smalfit_engine* engine, const float* prec, con
  * priors/joint_limits_prior.py:39-104 (commented out upstream: its table has 32 joints x 3 where view(34, 3) expects 34;
  * smalify_amd/model_io.py::joint_limit_table completes it).  host arrays: min (34,3), max (34,3), min <= max */
 int smalfit_engine_set_joint_limits(smalfit_engine* engine, const float* min_values, const float* max_values);
+/* back to the reference's behaviour (term commented out): w_limit is ignored again */
+int smalfit_engine_clear_joint_limits(smalfit_engine* engine);
 /* replaces: betas_prec / mean_betas          reference smal_fitter/smal_fitter.py:48-69
  * host arrays: prec (dim,dim), mean (dim); dim = 26 (unity prior: betas|log scales) or <= 20 */
 int smalfit_engine_set_shape_prior(smalfit_engine* engine, const float* prec, const float* mean, int dim);
@@ -168,8 +176,9 @@ int smalfit_project_points_backward(void* stream, int count, int image_size, con
  * with the reference's per-window normalisers, and writes every loss term plus the gradient of
  * their sum with respect to each parameter tensor. */
 typedef struct smalfit_fit_args {
+  unsigned struct_size;           /* sizeof(smalfit_fit_args) of the caller's header; checked by the library */
   int num_frames;                 /* M                                                          */
-  int window;                     /* WINDOW_SIZE; normalisers use the size of each frame's window */
+  int window;                     /* WINDOW_SIZE; normalisers use the size of each frame's window (see frame_offset) */
   int logscale_mode;              /* 0: no limb scales, 1: shared (6,), 2: per frame (M,6)       */
   int temporal;                   /* include the temporal term over these M frames              */
   int shape_prior_dim;            /* 0 = use the dim given to set_shape_prior                    */
@@ -200,6 +209,15 @@ typedef struct smalfit_fit_args {
   float w_limit;                  /* joint-limit hinge weight (OPT_WEIGHTS row 5).  Ignored -- like the reference, whose
                                      term is commented out while its weight table says 100 -- until
                                      smalfit_engine_set_joint_limits has been called                          */
+  /* Position of these M frames in their sequence.  The reference groups the frames of a SEQUENCE into consecutive windows
+   * of WINDOW_SIZE (optimize_to_joints.py:119-120, last one ragged) and normalises each window's terms by its size
+   * (smal_fitter.py:144,157,173).  An evaluation may hold any contiguous part of the sequence -- a shard, or ONE frame of
+   * an 8-frame window (one frame per GPU): local frame n is sequence frame frame_offset + n, its window is
+   * [w, min(w + window, total_frames)) with w = ((frame_offset + n) / window) * window.  The shape-prior term (once per
+   * window in the reference) is owned by the evaluation that holds the window's first frame.
+   * Zeros = the M frames are the whole sequence. */
+  int frame_offset;               /* index of local frame 0 in the sequence                     */
+  int total_frames;               /* frames in the whole sequence; 0 = frame_offset + num_frames */
 } smalfit_fit_args;
 
 int smalfit_fit_eval(smalfit_engine* engine, void* stream, const smalfit_fit_args* args);
@@ -237,6 +255,12 @@ int smalfit_adam_segments(void* stream, const smalfit_adam_args* adam);
  * Per iteration a rank evaluates its frames, steps its per-frame parameters, and contributes one record to an
  * all-gather: record = [partial gradient of the shared parameters (num_shared) | masked theta(105)|trans(3) of its first
  * frame | of its last frame] -- the partial shape gradient and the neighbours' temporal halo of the next iteration. */
+/* one rank's side of an iteration up to the collective, in ONE call: the evaluation (smalfit_fit_eval), Adam on the
+ * per-frame ranges (`adam_local`, t = step + 1) and the record (smalfit_shard_record with the parameters / masks of `args`)
+ * written straight into the collective's send buffer */
+int smalfit_shard_local_step(smalfit_engine* engine, void* stream, const smalfit_fit_args* args,
+                             const smalfit_adam_args* adam_local, int num_shared, const float* shared_grad,
+                             float* record /*(num_shared + 216)*/);
 int smalfit_shard_record(void* stream, int num_shared, const float* shared_grad, int num_frames,
                          const float* global_rotation, const float* joint_rotations, const float* trans,
                          const float* global_mask /*(3,)*/, const float* rotation_mask /*(34,3)*/,

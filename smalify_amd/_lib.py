@@ -11,6 +11,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 3                    # SMALFIT_ABI_VERSION of include/smalfit.h this binding mirrors
 LIB_PATH = os.environ.get("SMALFIT_LIB") or os.path.join(_HERE, "libsmalfit.so")   # override: development builds
 CSRC = os.path.join(_HERE, "csrc")
 
@@ -28,7 +29,7 @@ class ModelDesc(C.Structure):
 
 
 class FitArgs(C.Structure):
-    _fields_ = [("num_frames", C.c_int), ("window", C.c_int), ("logscale_mode", C.c_int),
+    _fields_ = [("struct_size", C.c_uint), ("num_frames", C.c_int), ("window", C.c_int), ("logscale_mode", C.c_int),
                 ("temporal", C.c_int), ("shape_prior_dim", C.c_int),
                 ("w_j2d", C.c_float), ("w_sil", C.c_float), ("w_betas", C.c_float),
                 ("w_pose", C.c_float), ("w_splay", C.c_float), ("w_temp", C.c_float),
@@ -40,7 +41,12 @@ class FitArgs(C.Structure):
                 ("g_betas", C.c_void_p), ("g_log_beta_scales", C.c_void_p),
                 ("g_global_rotation", C.c_void_p), ("g_joint_rotations", C.c_void_p),
                 ("g_trans", C.c_void_p), ("sil_out", C.c_void_p), ("proj_out", C.c_void_p),
-                ("verts_out", C.c_void_p), ("target_sil_u8", C.c_void_p), ("w_limit", C.c_float)]
+                ("verts_out", C.c_void_p), ("target_sil_u8", C.c_void_p), ("w_limit", C.c_float),
+                ("frame_offset", C.c_int), ("total_frames", C.c_int)]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = C.sizeof(FitArgs)
 
 
 class LbsArgs(C.Structure):
@@ -88,6 +94,7 @@ SIGNATURES = {
     "smalfit_engine_set_pose_prior": (_I, [_VP, _VP, _VP, _VP]),
     "smalfit_engine_set_shape_prior": (_I, [_VP, _VP, _VP, _I]),
     "smalfit_engine_set_joint_limits": (_I, [_VP, _VP, _VP]),
+    "smalfit_engine_clear_joint_limits": (_I, [_VP]),
     "smalfit_lbs_forward": (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "smalfit_lbs_backward": (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "smalfit_lbs_forward_ex": (_I, [_VP, _VP, C.POINTER(LbsArgs)]),
@@ -104,6 +111,7 @@ SIGNATURES = {
     "smalfit_fit_run": (_I, [_VP, _VP, C.POINTER(FitArgs), C.POINTER(AdamArgs), _I]),
     "smalfit_engine_set_graph": (_I, [_VP, _I]),
     "smalfit_adam_segments": (_I, [_VP, C.POINTER(AdamArgs)]),
+    "smalfit_shard_local_step": (_I, [_VP, _VP, C.POINTER(FitArgs), C.POINTER(AdamArgs), _I, _VP, _VP]),
     "smalfit_shard_record": (_I, [_VP, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "smalfit_shard_reduce_step": (_I, [_VP, _I, _I, _VP, _I, _I, C.POINTER(AdamArgs)]),
     "smalfit_pose_prior": (_I, [_VP, _VP, _I, _VP, _VP]),
@@ -162,6 +170,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    if lib.smalfit_version() != ABI_VERSION:
+        raise SmalfitError("%s has ABI version %d, this binding mirrors version %d of include/smalfit.h: rebuild the library"
+                           % (LIB_PATH, lib.smalfit_version(), ABI_VERSION))
     _lib = lib
     return lib
 

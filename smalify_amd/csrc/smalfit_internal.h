@@ -48,8 +48,20 @@ struct ModelDev {
   TreeLevels tree;
 };
 
+// Where the M frames of an evaluation sit in their sequence: frames are grouped into consecutive windows of `window`
+// frames counted from the START OF THE SEQUENCE (optimize_to_joints.py:119-120, the last window may be ragged), and the
+// reference's per-window normalisers 1/(B 50), 1/(B 105), 1/(B S^2) (smal_fitter.py:144,157,173) use the size B of the
+// window a frame belongs to.  An evaluation may hold any contiguous part of the sequence -- a whole sequence
+// (offset 0, total M), a shard of it, or a single frame of an 8-frame window (one frame per GPU).
+struct WinMap {
+  int window;   // WINDOW_SIZE
+  int offset;   // index of local frame 0 in the sequence
+  int total;    // frames in the whole sequence
+};
+
 struct LossArgs {
-  int M, S, window;
+  int M, S;
+  WinMap win;
   const float* theta;      // [M][105] masked
   const float* trans;      // [M][3]
   const float* joints;     // [M][41][3] (untranslated)
@@ -73,7 +85,8 @@ struct LossArgs {
 };
 
 struct AssembleArgs {
-  int M, S, T, window, nb, NBall, nblk_beta, nvt;
+  int M, S, T, nb, NBall, nblk_beta, nvt;
+  WinMap win;
   int betas_shared, ls_shared;
   float w_sil;
   const float* dbeta_part;

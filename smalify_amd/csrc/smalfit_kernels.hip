@@ -83,12 +83,12 @@ __device__ __forceinline__ float wave_sums(float* v, int lane) {
   return r;
 }
 
-__device__ __forceinline__ int frame_window_size(int n, int M, int window) {
-  // frames are grouped into consecutive windows of `window` frames, the last one may be ragged
-  // (optimize_to_joints.py:119-120)
-  const int start = (n / window) * window;
-  const int rem = M - start;
-  return rem < window ? rem : window;
+__device__ __forceinline__ int frame_window_size(int n, const WinMap& w) {
+  // size of the window local frame n belongs to: the sequence's frames are grouped into consecutive windows of
+  // `window` frames, the last one may be ragged (optimize_to_joints.py:119-120)
+  const int start = ((n + w.offset) / w.window) * w.window;
+  const int rem = w.total - start;
+  return rem < w.window ? rem : w.window;
 }
 
 #include "kernels_lbs_forward.inc"

@@ -18,8 +18,14 @@ collective, no torch arithmetic on the path.
 
 One latency-bound collective of ~1 KB per iteration on xGMI instead of an all-gather before and an all-reduce
 after the evaluation; there is no bulk exchange to overlap.  The temporal pair (i, i+1) is owned, for the loss
-value, by the rank that owns frame i.  Shards must start on window boundaries so that the per-window
-normalisers match the unsharded run.
+value, by the rank that owns frame i.
+
+Shards are ANY contiguous split of the sequence: the engine is told where its frames sit in the sequence
+(smalfit_fit_args.frame_offset / total_frames) and forms the reference's per-window normalisers 1/(B 50), 1/(B 105),
+1/(B S^2) (smal_fitter.py:144,157,173) from the SEQUENCE's windows (optimize_to_joints.py:119-120) -- so 64 frames go
+8 per GPU (BASELINE config 4), a ragged 61-frame clip goes 8,8,8,8,8,7,7,7, and the 8 frames of ONE window go one frame
+per GPU (the split north_star names).  The shape-prior term, which the reference evaluates once per window, is owned by
+the rank that holds the window's first frame; the sum over ranks is the sum over windows.
 """
 from __future__ import annotations
 
@@ -28,13 +34,17 @@ import torch.distributed as dist
 
 
 def shard_range(num_frames, rank, world_size, window=None):
-    """contiguous [lo, hi) of frames for `rank`; equal shards, optionally aligned to `window`"""
-    if num_frames % world_size != 0:
-        raise ValueError("num_frames (%d) must be divisible by the number of ranks (%d)" % (num_frames, world_size))
-    per = num_frames // world_size
-    if window is not None and world_size > 1 and per % window != 0:
-        raise ValueError("frames per rank (%d) must be a multiple of WINDOW_SIZE (%d)" % (per, window))
-    return rank * per, (rank + 1) * per
+    """contiguous [lo, hi) of the sequence's frames for `rank`: a balanced split (the first num_frames % world_size ranks
+    hold one frame more), every rank at least one frame.  `window` is accepted for callers that pass WINDOW_SIZE; shards
+    need no alignment to it (see the module docstring) -- when num_frames / world_size is a multiple of the window, as in
+    BASELINE config 4, the balanced split is window-aligned anyway."""
+    if not 0 <= rank < world_size:
+        raise ValueError("rank %d outside a world of %d" % (rank, world_size))
+    if num_frames < world_size:
+        raise ValueError("%d frame(s) cannot be split over %d ranks: every rank needs at least one" % (num_frames, world_size))
+    base, extra = divmod(num_frames, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
 
 
 SHARED_NAMES = ("betas", "log_beta_scales")

@@ -115,6 +115,10 @@ class Engine:
         """replay one captured iteration per fit_run step (HIP graph) instead of enqueueing its launches one by one"""
         check(self.lib.smalfit_engine_set_graph(self.handle, int(bool(enable))), "smalfit_engine_set_graph")
 
+    def clear_joint_limits(self):
+        """back to the reference's behaviour: the w_limit column is ignored (its term is commented out upstream)"""
+        check(self.lib.smalfit_engine_clear_joint_limits(self.handle), "smalfit_engine_clear_joint_limits")
+
     def set_joint_limits(self, min_values, max_values):
         """(34,3) lower / upper limits of the joint rotations for the w_limit term (reference smal_fitter.py:76-79,146-151)"""
         lo, hi = _host(min_values, np.float32).reshape(-1), _host(max_values, np.float32).reshape(-1)
@@ -150,7 +154,7 @@ class Engine:
                  temporal=True, global_mask=None, rotation_mask=None, halo_prev=None, halo_next=None,
                  losses=None, grads=None, want=("betas", "log_beta_scales", "global_rotation",
                                                 "joint_rotations", "trans"),
-                 sil_out=None, proj_out=None, verts_out=None):
+                 sil_out=None, proj_out=None, verts_out=None, frame_offset=0, total_frames=0):
         """One evaluation of sum_windows SMALFitter.forward + get_temporal and its gradient.
 
         weights = (w_j2d, w_sil, w_betas, w_pose, w_limit, w_splay) as in the reference's OPT_WEIGHTS columns
@@ -162,7 +166,7 @@ class Engine:
             target_visibility=target_visibility, target_sil=target_sil, weights=weights, w_temp=w_temp, window=window,
             temporal=temporal, global_mask=global_mask, rotation_mask=rotation_mask, halo_prev=halo_prev,
             halo_next=halo_next, losses=losses, grads=grads, want=want, sil_out=sil_out, proj_out=proj_out,
-            verts_out=verts_out)
+            verts_out=verts_out, frame_offset=frame_offset, total_frames=total_frames)
         check(self.lib.smalfit_fit_eval(self.handle, _stream(), C.byref(a)), "smalfit_fit_eval")
         return losses, grads
 
@@ -171,7 +175,7 @@ class Engine:
                        temporal=True, global_mask=None, rotation_mask=None, halo_prev=None, halo_next=None,
                        losses=None, grads=None, want=("betas", "log_beta_scales", "global_rotation",
                                                       "joint_rotations", "trans"),
-                       sil_out=None, proj_out=None, verts_out=None):
+                       sil_out=None, proj_out=None, verts_out=None, frame_offset=0, total_frames=0):
         """-> (smalfit_fit_args, losses, grads, keep-alive list): the argument block of smalfit_fit_eval / smalfit_fit_run.
         The block holds raw device pointers: the caller keeps the tensors alive for as long as it uses it."""
         M = int(global_rotation.shape[0])
@@ -197,6 +201,8 @@ class Engine:
         a = FitArgs()
         a.num_frames, a.window, a.logscale_mode, a.temporal = M, int(window), mode, int(bool(temporal))
         a.shape_prior_dim = 0
+        # where these M frames sit in their sequence (shards; zeros = they are the whole sequence)
+        a.frame_offset, a.total_frames = int(frame_offset), int(total_frames)
         a.w_j2d, a.w_sil, a.w_betas, a.w_pose, a.w_splay, a.w_temp = w_j2d, w_sil, w_betas, w_pose, w_splay, float(w_temp)
         a.betas, a.log_beta_scales = _ptr(betas), _ptr(log_beta_scales)
         a.global_rotation, a.joint_rotations, a.trans = _ptr(global_rotation), _ptr(joint_rotations), _ptr(trans)
@@ -414,6 +420,13 @@ def shard_record(num_shared, shared_grad, num_frames, global_rotation, joint_rot
     check(_lib.load().smalfit_shard_record(_stream(), int(num_shared), _ptr(shared_grad), int(num_frames), _ptr(global_rotation),
                                            _ptr(joint_rotations), _ptr(trans), _ptr(global_mask), _ptr(rotation_mask),
                                            _ptr(record)), "smalfit_shard_record")
+
+
+def shard_local_step(engine, fit_args, adam_args, num_shared, shared_grad, record):
+    """evaluation + Adam on the per-frame ranges + this rank's record, one library call (smalfit_shard_local_step); does not
+    advance adam_args.step (shard_reduce_step closes the iteration)"""
+    check(engine.lib.smalfit_shard_local_step(engine.handle, _stream(), C.byref(fit_args), C.byref(adam_args), int(num_shared),
+                                              _ptr(shared_grad), _ptr(record)), "smalfit_shard_local_step")
 
 
 def shard_reduce_step(world_size, record_stride, gathered, num_shared, num_trainable, adam_args):

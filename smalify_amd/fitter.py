@@ -36,12 +36,20 @@ class FusedFitter:
 
     def __init__(self, engine: eng.Engine, target_joints, target_visibility, target_sil, window_size,
                  use_unity_prior=True, mean_betas=None, mean_log_scales=None, allow_limb_scaling=True,
-                 rank=0, world_size=1, group=None, sil_storage="auto"):
+                 rank=0, world_size=1, group=None, sil_storage="auto", frame_offset=0, total_frames=None):
+        """frame_offset / total_frames: these N frames are frames [frame_offset, frame_offset + N) of a sequence of
+        total_frames (a shard of a sequence fitted by several ranks, smalify_amd/distributed.py): the reference's per-window
+        normalisers (smal_fitter.py:144,157,173) follow the SEQUENCE's windows (optimize_to_joints.py:119-120), so a shard
+        may start anywhere, down to one frame of a window per rank."""
         self.e = engine
         dev = engine.device
         self.N = int(target_joints.shape[0])
         self.S = engine.image_size
         self.window = int(window_size)
+        self.frame_offset = int(frame_offset)
+        self.total_frames = self.frame_offset + self.N if total_frames is None else int(total_frames)
+        if self.frame_offset < 0 or self.total_frames < self.frame_offset + self.N:
+            raise ValueError("frames [%d, %d) do not fit a sequence of %d" % (self.frame_offset, self.frame_offset + self.N, self.total_frames))
         self.unity = bool(use_unity_prior)
         self.allow_limb_scaling = allow_limb_scaling
         self.rank, self.world_size, self.group = rank, world_size, group
@@ -100,13 +108,16 @@ class FusedFitter:
         self.losses = torch.zeros(eng.NUM_LOSS_TERMS, **f32)
         self.step_count = 0
         self.halo_prev = self.halo_next = None
+        self.use_joint_limits = False          # opt-in (enable_joint_limits): the reference's term is commented out
 
     def enable_joint_limits(self, min_values=None, max_values=None):
         """switch on the joint-limit hinge the reference has commented out (smal_fitter.py:76-79,146-151): from then on
-        the w_limit column of the weight table (100 in stages 1-3, config.py:68) takes effect on this engine"""
+        the w_limit column of the weight table (100 in stages 1-3, config.py:68) takes effect in THIS fitter's evaluations
+        (other fitters on the same engine keep passing w_limit = 0, like the reference)"""
         if min_values is None:
             min_values, max_values = model_io.joint_limit_table()
         self.e.set_joint_limits(min_values, max_values)
+        self.use_joint_limits = True
 
     # ---- stage control (optimize_to_joints.py:96-110) --------------------------------------------------
     def trainable(self, stage_id):
@@ -140,6 +151,9 @@ class FusedFitter:
     # ---- one epoch (optimize_to_joints.py:113-137) ---------------------------------------------------------
     def _fit_args(self, weights, w_temp, stage_id, want, **outs):
         vis = self.visibility_stage0 if stage_id == 0 else self.visibility_full
+        if not self.use_joint_limits:          # the engine's limit table may belong to another fitter: w_limit is per call
+            weights = [float(w) for w in weights]
+            weights[4] = 0.0
         return self.e.build_fit_args(
             betas=self.p["betas"], log_beta_scales=self.p["log_beta_scales"],
             global_rotation=self.p["global_rotation"], joint_rotations=self.p["joint_rotations"],
@@ -147,7 +161,7 @@ class FusedFitter:
             target_sil=self.target_sil, weights=weights, w_temp=w_temp, window=self.window,
             temporal=True, global_mask=self.global_mask, rotation_mask=self.rotation_mask,
             halo_prev=self.halo_prev, halo_next=self.halo_next,
-            losses=self.losses, grads=self.g, want=want, **outs)
+            losses=self.losses, grads=self.g, want=want, frame_offset=self.frame_offset, total_frames=self.total_frames, **outs)
 
     def evaluate(self, weights, w_temp, stage_id, want=None, **outs):
         want = self.trainable(stage_id) if want is None else want
@@ -216,9 +230,7 @@ class FusedFitter:
         self._plan = plans
         fa, aa, _ = plans[key]
         aa.step = self.step_count
-        self.e.fit_run(fa, aa, 1)
-        eng.shard_record(self.num_shared(), self.grad, self.N, self.p["global_rotation"], self.p["joint_rotations"],
-                         self.p["trans"], self.global_mask, self.rotation_mask, record)
+        eng.shard_local_step(self.e, fa, aa, self.num_shared(), self.grad, record)
 
     def shared_step(self, gathered, world_size, lr, stage_id):
         """sum of the ranks' partial shared gradients + Adam on the shared parameters the stage trains; closes the
@@ -253,6 +265,12 @@ class FusedFitter:
             return (rec * self._brec_mask).view(2, 108)
         torch.mul(rec, self._brec_mask, out=out)
         return out.view(2, 108)
+
+    def target_sil_float(self):
+        """the target silhouettes as float32 in [0, 1], whichever way they are stored on the device (bytes hold 255 t)"""
+        if self.target_sil.dtype == torch.uint8:
+            return self.target_sil.to(torch.float32) / 255.0
+        return self.target_sil
 
     def snapshot(self):
         """-> (verts (N,V,3) translated, silhouettes (N,S,S), projected keypoints (N,25,2)) at the current parameters.

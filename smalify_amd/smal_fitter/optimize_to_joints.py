@@ -102,7 +102,7 @@ def fit_sequence(data, filenames, model_data, pose_prior, shape_prior, use_unity
         rev_rendered = engine.render_color(back, colour)
         # keypoints of the turned mesh: the canonical joints are vertices-independent here, so mark the front view's only
         overlay = rendered * 0.8 + rgb_dev * 0.2
-        sil_err = (1.0 - (fitter.target_sil - sil_r).abs()).unsqueeze(1).expand(-1, 3, -1, -1).cpu()
+        sil_err = (1.0 - (fitter.target_sil_float() - sil_r).abs()).unsqueeze(1).expand(-1, 3, -1, -1).cpu()   # smal_fitter.py:243, in [0, 1]
         vis_t = fitter.visibility_full
         collage = torch.cat([SMALFitter._draw_joints(rgb_dev, fitter.target_joints, vis_t),
                              SMALFitter._draw_joints(rendered, proj, vis_t), SMALFitter._draw_joints(overlay, proj, vis_t),

@@ -139,11 +139,16 @@ class SMALFitter(nn.Module):
             e.set_shape_prior(*self._shape_prior)
             if self.enable_joint_limits:                            # reference smal_fitter.py:76-79, commented out there
                 e.set_joint_limits(*model_io.joint_limit_table())
+            else:                                                   # a shared engine may carry another fitter's table
+                e.clear_joint_limits()
             e._pose_prior, e._shape_prior, e._fitter_priors = self.pose_prior._data, self._shape_prior, self
         return e
 
     def forward(self, batch_range, weights, stage_id):
-        total, losses = _WindowLoss.apply(self, list(batch_range), [float(w) for w in weights], self.betas,
+        weights = [float(w) for w in weights]
+        if not self.enable_joint_limits:        # like the reference: the weight table says 100, the term does not exist
+            weights[4] = 0.0
+        total, losses = _WindowLoss.apply(self, list(batch_range), weights, self.betas,
                                           self.log_beta_scales, self.global_rotation, self.joint_rotations, self.trans)
         w_j2d, w_reproj, w_betas, w_pose, w_limit, w_splay = [float(w) for w in weights]
         active = dict(joint=w_j2d > 0, pose=w_pose > 0, splay=w_splay > 0, betas=w_betas > 0, sil_reproj=w_reproj > 0)

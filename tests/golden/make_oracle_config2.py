@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/oracle_config2_f64.npz / oracle_config2_f32.npz: the ORACLE's run of the reference's FULL 4-stage
+schedule (150/400/600/800 iterations, reference config.py:63-72) on BASELINE.json config 2's shape -- 8 frames, 256 x 256,
+WINDOW_SIZE 8 -- once in float64 and once in float32: the per-iteration per-term loss trace, the parameters at the start
+of every stage and at the end.  tests/config2_case.py defines the problem; tests/test_gpu_config2.py compares the HIP loop
+with the float64 run and uses the float32 run as the yardstick for what float32 arithmetic alone does to the end state.
+
+This is a cache of ORACLE output (oracle/smal_oracle.py, pinned to the reference by tests/test_oracle_golden.py), not
+reference output.  Hours of CPU: run in the build container, one process per precision:
+
+    python tests/golden/make_oracle_config2.py f64 [threads]      (about 1.5-2 h on 3 threads)
+    python tests/golden/make_oracle_config2.py f32 [threads]
+
+Progress is checkpointed to /tmp/oracle_config2_<tag>.ckpt every 25 iterations (rerun to continue) and a partial fixture
+(complete = False) is written every 100 iterations.
+"""
+import os
+import pickle
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from tests import config2_case as c2       # noqa: E402
+
+
+def write(tag, dtype, fp, tg, trace, stage_start, final, complete):
+    out = {"trace": np.asarray(trace, np.float64), "schedule": np.array(c2.SCHEDULE), "fingerprint": np.array(fp),
+           "dtype": np.array(str(dtype)), "complete": np.array(complete)}
+    for s, p in stage_start.items():
+        for k, v in p.items():
+            out["stage%d_%s" % (s, k)] = v
+    for k, v in (final or {}).items():
+        out["final_" + k] = v
+    if tag == "f64":                       # the targets travel with the float64 fixture (64 KB of packed bits)
+        out["tj"], out["vis"], out["tsil_bits"] = tg["tj"], tg["vis"], np.packbits(tg["tsil"].reshape(-1))
+    tmp = c2.fixture_path(tag) + ".tmp.npz"
+    np.savez_compressed(tmp, **out)
+    os.replace(tmp, c2.fixture_path(tag))
+
+
+def main():
+    tag = sys.argv[1]
+    torch.set_num_threads(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+    dtype = {"f64": torch.float64, "f32": torch.float32}[tag]
+    md, tg = c2.targets()
+    start = c2.initial_params()
+    fp = c2.fingerprint(tg, start)
+    prob = c2.problem(md, tg, dtype)
+    ckpt = "/tmp/oracle_config2_%s.ckpt" % tag
+    state = None
+    if os.path.exists(ckpt):
+        saved = pickle.load(open(ckpt, "rb"))
+        if saved["fp"] == fp:
+            state = saved["state"]
+            print("resuming at stage %d iteration %d" % (state["stage"], state["it"]), flush=True)
+    t0 = time.time()
+
+    def checkpoint(st):
+        n = len(st["trace"])
+        if n % 25 == 0:
+            pickle.dump({"fp": fp, "state": st}, open(ckpt + ".tmp", "wb"))
+            os.replace(ckpt + ".tmp", ckpt)
+            print("%s  %4d / %d  total %.6f  (%.0f s)" % (tag, n, sum(c2.SCHEDULE), sum(st["trace"][-1]), time.time() - t0), flush=True)
+        if n % 100 == 0:
+            write(tag, dtype, fp, tg, st["trace"], st["stage_start"], None, False)
+
+    trace, stage_start, final = c2.oracle_schedule(prob, start, dtype, checkpoint=checkpoint, state=state)
+    write(tag, dtype, fp, tg, trace, stage_start, final, True)
+    print("wrote", c2.fixture_path(tag), "final total", trace[-1].sum())
+
+
+if __name__ == "__main__":
+    main()

@@ -1,6 +1,8 @@
-"""CPU, world_size = 2, gloo: the frame-sharding layer (smalify_amd/distributed.py) must reproduce the
+"""CPU, world_size = 2 / 3 / 8, gloo: the frame-sharding layer (smalify_amd/distributed.py) must reproduce the
 unsharded optimisation: halo exchange for the temporal pairs that straddle the shard boundary, all-reduce of
-the shared shape gradient, identical Adam state on both ranks.
+the shared shape gradient, identical Adam state on every rank -- for window-aligned shards (BASELINE config 4: 64 frames,
+8 per rank), for ONE frame of an 8-frame window per rank (the split north_star names) and for ragged shards that cut
+through windows.
 
 The per-rank compute engine here is the ORACLE (torch CPU) wrapped in the local-fitter protocol that
 FusedFitter implements on the GPU — the test targets the distributed logic, not the kernels."""
@@ -26,7 +28,7 @@ class OracleLocalFitter:
         self.prob = so.FitProblem(m, prob_full.S, prob_full.tj[lo:hi].numpy(), prob_full.vis[lo:hi].numpy(),
                                   prob_full.sil[lo:hi].numpy(), prob_full.pose_prec.numpy(), prob_full.pose_mean.numpy(),
                                   prob_full.pose_mask.numpy(), prob_full.shape_prec.numpy(), prob_full.shape_mean.numpy(),
-                                  window, True)
+                                  window, True, frame_offset=lo, total_frames=prob_full.N)
         self.N = hi - lo
         self.p = {k: (v[lo:hi].clone() if v.shape[0] == prob_full.N and v.dim() > 1 else v.clone())
                   for k, v in params_full.items()}
@@ -82,17 +84,17 @@ class OracleLocalFitter:
         self.opt.step(self.p, {k: self.grads[k] for k in names})
 
 
-def _problem():
+def _problem(N=4, window=2):
     sys.path.insert(0, ROOT)
     from oracle import smal_oracle as so
     from smalify_amd import model_io, synthetic
     md = synthetic.synthetic_model()
     om = so.OracleModel(md)
     rs = np.random.RandomState(5)
-    N, S = 4, 32
+    S = 32
     pp, sp = synthetic.synthetic_pose_prior(), synthetic.synthetic_shape_prior()
     prob = so.FitProblem(om, S, rs.rand(N, 25, 2) * S, (rs.rand(N, 25) < 0.8).astype(np.float64), np.zeros((N, S, S)),
-                         pp[0], pp[1], pp[2], sp[0], sp[1], 2, True)
+                         pp[0], pp[1], pp[2], sp[0], sp[1], window, True)
     init = model_io.initial_global_rotation()
     params = dict(betas=torch.from_numpy(sp[1][:20]).double(), log_beta_scales=torch.from_numpy(sp[1][20:26]).double(),
                   global_rotation=torch.from_numpy(np.tile(init, (N, 1)) + 0.1 * rs.randn(N, 3)).double(),
@@ -101,15 +103,15 @@ def _problem():
     return prob, params
 
 
-def _worker(rank, world, port, out_q):
+def _worker(rank, world, port, out_q, N=4, window=2):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
     from smalify_amd import config as cfg, distributed
-    torch.set_num_threads(2)
-    prob, params = _problem()
-    lo, hi = distributed.shard_range(prob.N, rank, world, window=2)
-    f = distributed.ShardedFitter(OracleLocalFitter(prob, params, lo, hi, 2), rank, world)
+    torch.set_num_threads(1 if world > 2 else 2)
+    prob, params = _problem(N, window)
+    lo, hi = distributed.shard_range(prob.N, rank, world, window=window)
+    f = distributed.ShardedFitter(OracleLocalFitter(prob, params, lo, hi, window), rank, world)
     W = np.array(cfg.OPT_WEIGHTS).T
     w1 = W[1][:6].copy()
     w1[1] = 0.0
@@ -117,42 +119,46 @@ def _worker(rank, world, port, out_q):
         f.begin_stage(stage_id)
         for _ in range(its):
             f.step(W[0][:6] if stage_id == 0 else w1, float(W[stage_id][6]), float(W[stage_id][8]), stage_id)
-    out_q.put((rank, {k: v.numpy() for k, v in f.fitter.p.items()}))
+    out_q.put((rank, (lo, hi), {k: v.numpy() for k, v in f.fitter.p.items()}))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_fit_matches_single_process():
+# (frames, WINDOW_SIZE, ranks): window-aligned halves; BASELINE config 4's partition (64 frames, 8 per rank); ONE frame of
+# an 8-frame window per rank; ragged shards 3 + 2 + 2 cutting through windows of 4 (the last window is short)
+@pytest.mark.parametrize("N,window,world", [(4, 2, 2), (64, 8, 8), (8, 8, 8), (7, 4, 3)])
+def test_sharded_fit_matches_single_process(N, window, world):
     sys.path.insert(0, ROOT)
     from oracle import smal_oracle as so
     from smalify_amd import config as cfg
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + 7 * world + N
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, N, window)) for r in range(world)]
     for p in procs:
         p.start()
     import queue as _queue
-    results = {}
+    results, ranges = {}, {}
     try:
-        for _ in range(400):
+        for _ in range(600):
             try:
-                r, val = q.get(timeout=1.0)
-                results[r] = val
+                r, rng, val = q.get(timeout=1.0)
+                results[r], ranges[r] = val, rng
             except _queue.Empty:
                 if any(p.exitcode not in (None, 0) for p in procs):
                     break
-            if len(results) == 2:
+            if len(results) == world:
                 break
     finally:
         for p in procs:
-            p.join(timeout=30)
+            p.join(timeout=60)
             if p.is_alive():
                 p.terminate()
-    assert len(results) == 2, "a rank failed"
+    assert len(results) == world, "a rank failed"
     assert all(p.exitcode == 0 for p in procs)
+    assert [ranges[r][0] for r in range(world)] == [0] + [ranges[r][1] for r in range(world - 1)] and ranges[world - 1][1] == N
     # single-process oracle run of the same schedule
-    prob, params = _problem()
+    prob, params = _problem(N, window)
     W = np.array(cfg.OPT_WEIGHTS).T
     w1 = W[1][:6].copy()
     w1[1] = 0.0
@@ -163,20 +169,50 @@ def test_two_rank_sharded_fit_matches_single_process():
                                             so.trainable_names(stage_id))
             opt.step(params, grads)
     for k in ("betas", "log_beta_scales"):
-        for r in (0, 1):
+        for r in range(world):
+            assert np.array_equal(results[r][k], results[0][k]), (k, r)          # the same bits on every rank
             assert np.allclose(results[r][k], params[k].numpy(), rtol=1e-9, atol=1e-12), (k, r)
     for k in ("global_rotation", "trans", "joint_rotations"):
-        got = np.concatenate([results[0][k], results[1][k]], 0)
+        got = np.concatenate([results[r][k] for r in range(world)], 0)
         assert np.allclose(got, params[k].numpy(), rtol=1e-9, atol=1e-12), k
+
+
+def test_oracle_shards_add_up_to_the_sequence():
+    """the shard-aware form of the oracle's epoch loss (FitProblem.frame_offset / total_frames) is a partition of the
+    reference's sum over windows: per-term sums over any contiguous split equal the whole sequence's"""
+    sys.path.insert(0, ROOT)
+    from oracle import smal_oracle as so
+    from smalify_amd import config as cfg, distributed
+    prob, params = _problem(7, 4)
+    W = np.array(cfg.OPT_WEIGHTS).T
+    w1 = W[1][:6].copy()
+    w1[1] = 0.0
+    _, full = so.epoch_loss(prob, params, w1, 0.0)
+    for world in (2, 3, 7):
+        acc = {}
+        for r in range(world):
+            lo, hi = distributed.shard_range(7, r, world)
+            part = so.FitProblem(prob.m, prob.S, prob.tj[lo:hi].numpy(), prob.vis[lo:hi].numpy(), prob.sil[lo:hi].numpy(),
+                                 prob.pose_prec.numpy(), prob.pose_mean.numpy(), prob.pose_mask.numpy(), prob.shape_prec.numpy(),
+                                 prob.shape_mean.numpy(), 4, True, frame_offset=lo, total_frames=7)
+            pp = {k: (v[lo:hi] if v.dim() > 1 else v) for k, v in params.items()}
+            _, sums = so.epoch_loss(part, pp, w1, 0.0)
+            for k, v in sums.items():
+                acc[k] = acc.get(k, 0.0) + float(v)
+        for k in ("joint", "pose", "splay", "betas"):
+            assert abs(acc[k] - float(full[k])) < 1e-9 * max(1.0, abs(float(full[k]))), (world, k, acc[k], float(full[k]))
 
 
 def test_shard_range_validation():
     from smalify_amd import distributed
     assert distributed.shard_range(64, 3, 8, window=8) == (24, 32)
+    assert [distributed.shard_range(8, r, 8, window=8) for r in range(8)] == [(r, r + 1) for r in range(8)]   # one frame per rank
+    sizes = [hi - lo for lo, hi in (distributed.shard_range(61, r, 8, window=8) for r in range(8))]
+    assert sizes == [8, 8, 8, 8, 8, 7, 7, 7] and distributed.shard_range(61, 7, 8)[1] == 61                   # ragged clip
     with pytest.raises(ValueError):
-        distributed.shard_range(64, 0, 3)
+        distributed.shard_range(3, 0, 4)            # fewer frames than ranks
     with pytest.raises(ValueError):
-        distributed.shard_range(64, 0, 8, window=16)
+        distributed.shard_range(64, 8, 8)
 
 
 def test_world_of_one_with_the_collective_equals_the_plain_step():

@@ -314,3 +314,19 @@ def test_fit_sequence_runs_the_schedule_and_writes_the_final_files(golden, md, t
             d = pickle.load(fh)
         assert d["joint_rotations"].shape == (34, 3) and d["joint_rotations"].dtype == np.float32
     assert np.isfinite(f.losses.cpu().numpy()).all()
+    # fourth panel = 1 - |target silhouette - rendered| in [0, 1] (reference smal_fitter.py:243).  The all-zero masks of this
+    # sequence are stored as BYTES on the device (sil_storage "auto"): the panel must still be 1 - rendered, i.e. white
+    # where nothing is rendered and dark on the animal -- not a wrapped difference of byte values
+    import struct
+    import zlib
+    assert f.target_sil.dtype == torch.uint8
+    _, sil_r, _ = f.snapshot()
+    expect = np.clip((1.0 - sil_r.cpu().numpy()) * 255.0, 0, 255)
+    for i in range(N):
+        blob = open(os.path.join(str(tmp_path), "frame_%02d" % i, "st10_ep0.png"), "rb").read()
+        w, h = struct.unpack(">II", blob[16:24])
+        n = struct.unpack(">I", blob[33:37])[0]
+        rows = np.frombuffer(zlib.decompress(blob[41:41 + n]), np.uint8).reshape(h, 1 + 3 * w)[:, 1:].reshape(h, w, 3)
+        panel = rows[:, 3 * S:4 * S, 0].astype(np.float64)
+        assert np.abs(panel - expect[i]).max() <= 1.0, np.abs(panel - expect[i]).max()
+        assert (panel > 250).mean() > 0.5

@@ -1,5 +1,7 @@
-"""GPU test of the frame-sharded loop: two processes on one GPU (gloo moves the 1 KB records), each with a FusedFitter on
-half of the frames, against one process fitting all of them.  The collective itself is not the point here (RCCL is
+"""GPU test of the frame-sharded loop: several processes on one GPU (gloo moves the 1 KB records), each with a FusedFitter on
+its shard of the frames, against one process fitting all of them -- two halves; BASELINE config 4's partition (64 frames,
+WINDOW_SIZE 8, 8 ranks x 8 frames, 7 interior halos); ONE frame of an 8-frame window per rank (the split north_star names);
+ragged shards that cut through windows.  The collective itself is not the point here (RCCL is
 exercised by bench.py --gpus N on a multi-GPU node); the point is that ShardedFitter + the HIP engine with halo frames
 reproduce the unsharded fit."""
 import os
@@ -13,23 +15,23 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-N_FRAMES, SIZE, WINDOW = 8, 64, 4
+SIZE = 64
 SCHEDULE = ((0, 3), (1, 3), (2, 4))
 
 
-def _setup():
+def _setup(n_frames, window):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import parity_cases as pc
-    _, prob, cur, tg = pc.make_problem(N_FRAMES, SIZE, WINDOW, 21)
+    prob, cur, tg = pc.make_problem_cpu(n_frames, SIZE, window, 21)      # targets from the oracle; engines are made per shard
     return pc, cur, tg
 
 
-def _run(fitter_factory, rank, world):
+def _run(fitter_factory, rank, world, n_frames=8, window=4):
     from smalify_amd import config as cfg, distributed
-    pc, cur, tg = _setup()
-    lo, hi = distributed.shard_range(N_FRAMES, rank, world, window=WINDOW)
-    f = fitter_factory(pc, cur, tg, lo, hi)
+    pc, cur, tg = _setup(n_frames, window)
+    lo, hi = distributed.shard_range(n_frames, rank, world, window=window)
+    f = fitter_factory(pc, cur, tg, lo, hi, n_frames, window)
     sf = distributed.ShardedFitter(f, rank, world) if world > 1 else f
     W = np.array(cfg.OPT_WEIGHTS).T
     for stage_id, its in SCHEDULE:
@@ -39,19 +41,20 @@ def _run(fitter_factory, rank, world):
     return {k: v.detach().cpu().numpy().copy() for k, v in f.p.items()}
 
 
-def _factory(pc, cur, tg, lo, hi):
+def _factory(pc, cur, tg, lo, hi, n_frames, window):
     from smalify_amd import engine as eng, fitter as fit, synthetic
     _, _, dm = pc.get_model()
     e = eng.Engine(dm, hi - lo, SIZE)
     e.set_pose_prior(*synthetic.synthetic_pose_prior())
     e.set_shape_prior(*synthetic.synthetic_shape_prior())
-    f = fit.FusedFitter(e, tg["tj"][lo:hi], tg["vis"][lo:hi], tg["tsil"][lo:hi], WINDOW, True, cur["betas"], cur["log_beta_scales"])
+    f = fit.FusedFitter(e, tg["tj"][lo:hi], tg["vis"][lo:hi], tg["tsil"][lo:hi], window, True, cur["betas"], cur["log_beta_scales"],
+                        frame_offset=lo, total_frames=n_frames)
     for k in ("global_rotation", "joint_rotations", "trans"):
         f.p[k].copy_(pc.dev(cur[k][lo:hi]))
     return f
 
 
-def _worker(rank, world, port, q, backend="gloo"):
+def _worker(rank, world, port, q, backend="gloo", n_frames=8, window=4):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     if backend == "nccl":                       # RCCL: one GPU per rank
         torch.cuda.set_device(rank)
@@ -60,20 +63,36 @@ def _worker(rank, world, port, q, backend="gloo"):
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        q.put((rank, _run(_factory, rank, world)))
+        q.put((rank, _run(_factory, rank, world, n_frames, window)))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
 def test_two_ranks_on_one_gpu_match_the_unsharded_fit():
-    _two_ranks("gloo")
+    _ranks("gloo", 2, 8, 4)
+
+
+def test_config4_partition_eight_ranks_of_eight_frames():
+    """BASELINE config 4's real partition on one GPU: 64 frames, WINDOW_SIZE 8, 8 ranks x 8 frames (7 interior halos)"""
+    _ranks("gloo", 8, 64, 8)
+
+
+def test_one_frame_of_a_window_per_rank():
+    """the split north_star names: the 8 frames of ONE window, one frame per rank -- every rank normalises by the window's
+    8 frames, rank 0 owns the window's shape-prior term"""
+    _ranks("gloo", 8, 8, 8)
+
+
+def test_ragged_shards_cut_through_windows():
+    """7 frames, WINDOW_SIZE 4 (windows of 4 and 3), 3 ranks holding 3 + 2 + 2 frames"""
+    _ranks("gloo", 3, 7, 4)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL collective needs one GPU per rank")
 def test_two_ranks_over_rccl_match_the_unsharded_fit():
     """the same comparison with the record travelling over RCCL (backend "nccl") between two GPUs"""
-    _two_ranks("nccl")
+    _ranks("nccl", 2, 8, 4)
 
 
 def test_bench_launches_its_own_ranks():
@@ -97,12 +116,12 @@ def test_bench_launches_its_own_ranks():
     assert d["n_gpus"] == n and d["steps"] == 12 and d["value"] > 0 and d["status_bits"] == 0
 
 
-def _two_ranks(backend):
-    single = _run(_factory, 0, 1)
+def _ranks(backend, world, n_frames, window):
+    single = _run(_factory, 0, 1, n_frames, window)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 1000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend)) for r in range(2)]
+    port = 29700 + (os.getpid() % 1000) + 3 * world + n_frames
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend, n_frames, window)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
@@ -112,7 +131,7 @@ def _two_ranks(backend):
             try:
                 r, val = q.get(timeout=1.0)
                 got[r] = val
-                if len(got) == 2:
+                if len(got) == world:
                     break
             except _queue.Empty:
                 if any(p.exitcode not in (None, 0) for p in procs):
@@ -122,13 +141,14 @@ def _two_ranks(backend):
             p.join(timeout=60)
             if p.is_alive():
                 p.kill()
-    assert len(got) == 2, "a rank died: exit codes %s" % [p.exitcode for p in procs]
-    half = N_FRAMES // 2
+    assert len(got) == world, "a rank died: exit codes %s" % [p.exitcode for p in procs]
     for k in ("global_rotation", "joint_rotations", "trans"):
-        both = np.concatenate([got[0][k], got[1][k]], 0)
+        both = np.concatenate([got[r][k] for r in range(world)], 0)
+        assert both.shape == single[k].shape
         err = np.linalg.norm(both - single[k]) / np.linalg.norm(single[k])
         assert err < 2e-5, (k, err)
     for k in ("betas", "log_beta_scales"):
-        assert np.array_equal(got[0][k], got[1][k]), k            # shared parameters: identical bits on both ranks
+        for r in range(1, world):
+            assert np.array_equal(got[0][k], got[r][k]), (k, r)   # shared parameters: identical bits on every rank
         err = np.linalg.norm(got[0][k] - single[k]) / np.linalg.norm(single[k])
         assert err < 2e-5, (k, err)
