@@ -10,6 +10,7 @@ reference output.  Hours of CPU: run in the build container, one process per pre
 
     python tests/golden/make_oracle_config2.py f64 [threads]      (about 1.5-2 h on 3 threads)
     python tests/golden/make_oracle_config2.py f32 [threads]
+    python tests/golden/make_oracle_config2.py heads [threads]    (after f64: minutes; see heads())
 
 Progress is checkpointed to /tmp/oracle_config2_<tag>.ckpt every 25 iterations (rerun to continue) and a partial fixture
 (complete = False) is written every 100 iterations.
@@ -41,8 +42,44 @@ def write(tag, dtype, fp, tg, trace, stage_start, final, complete):
     os.replace(tmp, c2.fixture_path(tag))
 
 
+HEAD_ITERS = 24
+
+
+def heads():
+    """oracle_config2_heads.npz: the float32 ORACLE's first HEAD_ITERS iterations of every stage, started from the float64
+    run's state at the start of that stage -- what float32 arithmetic alone does to the loss trace over the window in
+    which tests/test_gpu_config2.py compares the HIP loop with the float64 trace (the yardstick of that comparison)."""
+    import numpy as np
+    from oracle import smal_oracle as so
+    from smalify_amd import config as cfg
+    f64 = c2.load_fixture("f64")
+    md, tg = c2.targets()
+    assert f64 is not None and f64["fingerprint"] == c2.fingerprint(tg, c2.initial_params())
+    prob = c2.problem(md, tg, torch.float32)
+    W = np.array(cfg.OPT_WEIGHTS).T
+    out = {"fingerprint": np.array(f64["fingerprint"]), "head_iters": np.array(HEAD_ITERS)}
+    for stage, start in sorted(f64["stage_start"].items()):
+        params = {k: torch.from_numpy(np.asarray(v)).to(torch.float32) for k, v in start.items()}
+        w = W[stage]
+        names = so.trainable_names(stage)
+        vis = so.stage0_visibility(prob.vis) if stage == 0 else None
+        opt = so.Adam(so.PARAM_ORDER, lr=float(w[8]))
+        rows = []
+        for _ in range(HEAD_ITERS):
+            total, sums, grads = so.loss_and_grads(prob, params, w[:6].copy(), float(w[6]), names, visibility=vis)
+            rows.append([float(sums.get(k, 0.0)) for k in c2.TERMS])
+            opt.step(params, grads)
+        out["stage%d_f32_trace" % stage] = np.array(rows)
+        print("heads: stage", stage, "done", flush=True)
+    np.savez_compressed(c2.fixture_path("heads"), **out)
+    print("wrote", c2.fixture_path("heads"))
+
+
 def main():
     tag = sys.argv[1]
+    if tag == "heads":
+        torch.set_num_threads(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+        return heads()
     torch.set_num_threads(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
     dtype = {"f64": torch.float64, "f32": torch.float32}[tag]
     md, tg = c2.targets()

@@ -1,0 +1,140 @@
+"""BASELINE.json config 2's shape on the GPU -- 8 frames, 256 x 256, WINDOW_SIZE 8, the reference's FULL 150/400/600/800
+schedule (config.py:63-72) from the reference's initial state -- against the oracle's float64 run of the same problem
+(tests/golden/oracle_config2_f64.npz, made by tests/golden/make_oracle_config2.py; tests/config2_case.py defines the
+problem and tests/test_oracle_golden.py pins the fixture to today's oracle).
+
+What is asserted, and why these bounds:
+  (i)   loss trace: from the oracle's own state at the start of EVERY stage, the first HEAD iterations of the HIP loop
+        (losses + analytic gradients + Adam, silhouette and rasteriser cache included) reproduce the float64 trace of totals
+        to TRACE_TOL relative -- north_star's 1e-4 -- for the first STRICT iterations unconditionally, and beyond that
+        wherever float32 arithmetic allows it: stage 1 (lr 5e-3, every parameter on a fresh Adam) goes through a loss spike
+        around its 15th iteration in which the ORACLE ITSELF run in float32 from the same state leaves the float64 trace
+        by 5.6e-3 (tests/golden/oracle_config2_heads.npz, `make_oracle_config2.py heads`); there the bound is
+        DRIFT_FACTOR x the float32 oracle's own deviation so far.
+  (ii)  the whole 1950-iteration fit from the reference's initial state: final per-term losses against the float64 run.
+  (iii) end-of-run parameters: the fit is a chaotic map over ~2000 Adam steps (a gradient component whose sign differs in
+        the last float32 bit becomes a +-lr step), so float32 arithmetic alone carries ANY implementation away from the
+        float64 run.  The yardstick is the oracle itself run in float32 (oracle_config2_f32.npz): per parameter tensor,
+        ||HIP - f64|| <= DRIFT_FACTOR x ||f32 oracle - f64||, at the end of every stage and of the run.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HEAD = 20
+STRICT = 12
+TRACE_TOL = 1e-4
+DRIFT_FACTOR = 1.5
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64).reshape(-1), np.asarray(b, np.float64).reshape(-1)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def case():
+    from tests import config2_case as c2
+    f64 = c2.load_fixture("f64")
+    if f64 is None or "targets" not in f64:
+        pytest.skip("tests/golden/oracle_config2_f64.npz missing: run tests/golden/make_oracle_config2.py f64")
+    from smalify_amd import config as cfg, engine as eng, fitter as fit, synthetic
+    md = synthetic.synthetic_model(seed=0, shape_family_id=1)
+    e = eng.Engine(eng.DeviceModel(md), c2.FRAMES, c2.IMAGE_SIZE)
+    e.set_pose_prior(*synthetic.synthetic_pose_prior())
+    sp = synthetic.synthetic_shape_prior()
+    e.set_shape_prior(*sp)
+    tg = f64["targets"]
+
+    def new_fitter(start):
+        e.reset_raster_cache()
+        f = fit.FusedFitter(e, tg["tj"], tg["vis"], tg["tsil"].astype(np.float32), c2.WINDOW, True, start["betas"], start["log_beta_scales"])
+        for k in ("global_rotation", "joint_rotations", "trans"):
+            f.p[k].copy_(torch.as_tensor(np.asarray(start[k], np.float32)).cuda().reshape(f.p[k].shape))
+        return f
+
+    import os
+    heads = np.load(c2.fixture_path("heads"), allow_pickle=False) if os.path.exists(c2.fixture_path("heads")) else None
+    return dict(c2=c2, f64=f64, f32=c2.load_fixture("f32"), heads=heads, new_fitter=new_fitter, W=np.array(cfg.OPT_WEIGHTS).T, e=e)
+
+
+def test_fixture_matches_the_problem(case):
+    c2, f64 = case["c2"], case["f64"]
+    assert f64["fingerprint"] == c2.fingerprint(f64["targets"], c2.initial_params())
+    assert f64["schedule"] == c2.SCHEDULE
+
+
+def test_loss_trace_follows_the_float64_oracle_at_the_head_of_every_stage(case):
+    c2, f64, W = case["c2"], case["f64"], case["W"]
+    starts = np.concatenate([[0], np.cumsum(c2.SCHEDULE)])
+    heads = case["heads"]
+    if heads is None or str(heads["fingerprint"]) != f64["fingerprint"]:
+        pytest.skip("tests/golden/oracle_config2_heads.npz missing or stale: run tests/golden/make_oracle_config2.py heads")
+    worst = {}
+    for stage in range(4):
+        if stage not in f64["stage_start"] or len(f64["trace"]) < starts[stage] + HEAD:
+            break                       # partial fixture (the generator writes one every 100 iterations)
+        f = case["new_fitter"](f64["stage_start"][stage])
+        f.begin_stage(stage)
+        w = W[stage]
+        dev = []
+        for it in range(HEAD):
+            f.step(w[:6], float(w[6]), float(w[8]), stage)
+            hip = float(f.losses.double().sum().item())
+            ref = float(f64["trace"][starts[stage] + it].sum())
+            dev.append(abs(hip - ref) / abs(ref))
+        if "stage%d_f32_trace" % stage not in heads.files:
+            break
+        ref64 = f64["trace"][starts[stage]:starts[stage] + HEAD].sum(1)
+        yard = np.abs(heads["stage%d_f32_trace" % stage][:HEAD + 1].sum(1)[:HEAD] - ref64) / np.abs(ref64)
+        worst[stage] = (dev, yard)
+        print("config 2, stage %d, loss trace vs float64 oracle, %d iterations:\n   HIP        %s\n   f32 oracle %s"
+              % (stage, HEAD, " ".join("%.0e" % d for d in dev), " ".join("%.0e" % d for d in yard)))
+    assert case["e"].status() == 0 and worst
+    for stage, (dev, yard) in worst.items():
+        for it in range(HEAD):
+            bound = TRACE_TOL if it < STRICT else max(TRACE_TOL, DRIFT_FACTOR * float(np.max(yard[:min(HEAD, it + 2)])))
+            assert dev[it] < bound, (stage, it, dev[it], bound)
+
+
+def test_full_schedule_end_state_within_the_float32_yardstick(case):
+    c2, f64, f32, W = case["c2"], case["f64"], case["f32"], case["W"]
+    if f32 is None:
+        pytest.skip("tests/golden/oracle_config2_f32.npz missing: run tests/golden/make_oracle_config2.py f32")
+    f = case["new_fitter"](c2.initial_params())
+    ends = {}
+    for stage in range(4):
+        f.begin_stage(stage)
+        w = W[stage]
+        f.run_iterations(w[:6], float(w[6]), float(w[8]), stage, c2.SCHEDULE[stage])
+        ends[stage] = ({k: f.p[k].cpu().numpy().astype(np.float64) for k in c2.PARAMS}, f.losses.cpu().numpy().astype(np.float64))
+    assert case["e"].status() == 0
+    checked = 0
+    for stage in range(4):
+        # the state at the END of stage s is the oracle's state at the START of stage s + 1 (or `final`)
+        ref64 = f64["stage_start"].get(stage + 1) if stage < 3 else (f64["final"] or None)
+        ref32 = f32["stage_start"].get(stage + 1) if stage < 3 else (f32["final"] or None)
+        if not ref64 or not ref32:
+            continue
+        checked += 1
+        for k in c2.PARAMS:
+            hip, yard = _rel(ends[stage][0][k], ref64[k]), _rel(ref32[k], ref64[k])
+            print("config 2, end of stage %d, %-16s rel-L2: HIP vs f64 %.2e   f32 oracle vs f64 %.2e" % (stage, k, hip, yard))
+            assert hip <= DRIFT_FACTOR * yard + 1e-6, (stage, k, hip, yard)
+    if checked == 0:
+        pytest.skip("fixtures incomplete: no stage end available yet")
+    if f64["complete"] and f32["complete"]:
+        # final per-term losses: the last trace row is the evaluation BEFORE the last update, like FusedFitter.losses
+        ref, ref32 = f64["trace"][-1], f32["trace"][-1]
+        hip = ends[3][1][:8]
+        for i, name in enumerate(c2.TERMS):
+            if abs(ref[i]) < 1e-12:
+                continue
+            d, y = abs(hip[i] - ref[i]) / abs(ref[i]), abs(ref32[i] - ref[i]) / abs(ref[i])
+            print("config 2, final %-12s HIP %.6f  f64 %.6f  rel %.2e   (f32 oracle rel %.2e)" % (name, hip[i], ref[i], d, y))
+            assert d <= DRIFT_FACTOR * y + 1e-4, (name, d, y)
+        dt, yt = abs(hip.sum() - ref.sum()) / ref.sum(), abs(ref32.sum() - ref.sum()) / ref.sum()
+        print("config 2, final total: HIP %.6f  f64 %.6f  rel %.2e   (f32 oracle rel %.2e)" % (hip.sum(), ref.sum(), dt, yt))
+        assert dt <= DRIFT_FACTOR * yt + 1e-4

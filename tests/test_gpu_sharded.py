@@ -19,17 +19,41 @@ SIZE = 64
 SCHEDULE = ((0, 3), (1, 3), (2, 4))
 
 
-def _setup(n_frames, window):
+def _problem(n_frames, seed=21):
+    """start parameters and targets of a synthetic sequence, made ONCE by the parent and handed to every rank: targets are
+    rendered by the engine itself from a ground-truth pose (the comparison here is sharded vs unsharded, not HIP vs oracle;
+    the oracle's CPU rasteriser would take minutes for 64 frames in each of 9 processes)"""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import parity_cases as pc
-    prob, cur, tg = pc.make_problem_cpu(n_frames, SIZE, window, 21)      # targets from the oracle; engines are made per shard
-    return pc, cur, tg
+    from smalify_amd import engine as eng
+    gt = pc.random_pose(n_frames, seed)
+    cur = pc.random_pose(n_frames, seed)
+    rs = np.random.RandomState(seed + 7)
+    cur["global_rotation"] += (0.05 * rs.randn(n_frames, 3)).astype(np.float32)
+    cur["joint_rotations"] += (0.08 * rs.randn(n_frames, 34, 3)).astype(np.float32)
+    cur["trans"] += (0.02 * rs.randn(n_frames, 3)).astype(np.float32)
+    cur["betas"] += (0.1 * rs.randn(20)).astype(np.float32)
+    _, _, dm = pc.get_model()
+    e = eng.Engine(dm, n_frames, SIZE)
+    sil = torch.empty(n_frames, SIZE, SIZE, device="cuda")
+    proj = torch.empty(n_frames, 25, 2, device="cuda")
+    d = {k: pc.dev(v) for k, v in gt.items()}
+    e.fit_eval(betas=d["betas"], log_beta_scales=d["log_beta_scales"], global_rotation=d["global_rotation"],
+               joint_rotations=d["joint_rotations"], trans=d["trans"], target_joints=None, target_visibility=None, target_sil=None,
+               weights=(0, 0, 0, 0, 0, 0), w_temp=0.0, window=1, want=(), sil_out=sil, proj_out=proj)
+    vis = (rs.rand(n_frames, 25) < 0.85).astype(np.float32)
+    tg = dict(tj=(proj.cpu().numpy() + rs.randn(n_frames, 25, 2)).astype(np.float32), vis=vis,
+              tsil=(sil > 0.5).float().cpu().numpy())
+    assert e.status() == 0 and 0.02 < tg["tsil"].mean() < 0.9
+    return cur, tg
 
 
-def _run(fitter_factory, rank, world, n_frames=8, window=4):
+def _run(fitter_factory, rank, world, n_frames, window, cur, tg):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity_cases as pc
     from smalify_amd import config as cfg, distributed
-    pc, cur, tg = _setup(n_frames, window)
     lo, hi = distributed.shard_range(n_frames, rank, world, window=window)
     f = fitter_factory(pc, cur, tg, lo, hi, n_frames, window)
     sf = distributed.ShardedFitter(f, rank, world) if world > 1 else f
@@ -54,7 +78,8 @@ def _factory(pc, cur, tg, lo, hi, n_frames, window):
     return f
 
 
-def _worker(rank, world, port, q, backend="gloo", n_frames=8, window=4):
+def _worker(rank, world, port, q, backend, n_frames, window, cur, tg):
+    torch.set_num_threads(1)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     if backend == "nccl":                       # RCCL: one GPU per rank
         torch.cuda.set_device(rank)
@@ -63,7 +88,7 @@ def _worker(rank, world, port, q, backend="gloo", n_frames=8, window=4):
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        q.put((rank, _run(_factory, rank, world, n_frames, window)))
+        q.put((rank, _run(_factory, rank, world, n_frames, window, cur, tg)))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -117,17 +142,18 @@ def test_bench_launches_its_own_ranks():
 
 
 def _ranks(backend, world, n_frames, window):
-    single = _run(_factory, 0, 1, n_frames, window)
+    cur, tg = _problem(n_frames)
+    single = _run(_factory, 0, 1, n_frames, window, cur, tg)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29700 + (os.getpid() % 1000) + 3 * world + n_frames
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend, n_frames, window)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend, n_frames, window, cur, tg)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
     try:
         import queue as _queue
-        for _ in range(600):
+        for _ in range(240):
             try:
                 r, val = q.get(timeout=1.0)
                 got[r] = val
