@@ -17,8 +17,10 @@ timing  : W untimed warm-up steps, then EXACTLY K steps between (barrier +) torc
           forgotten (smalfit_engine_reset_raster_cache) before the timed fit starts, so the fit pays its first exact
           K-nearest selection inside the timed region, exactly like a fit of a new sequence does.  `value_primed` is a
           second, separately timed run of the same K steps after ONE untimed silhouette evaluation of the initial state --
-          what a K-step window in the middle of a long fit looks like (the cold selection is paid once per 1950-step
-          fit: at K = 20 it is ~5 % of the window, at K = 1950 nothing).
+          what a K-step window in the middle of a long fit looks like.  Neither region carries instrumentation beyond five
+          stream events at the stage boundaries; the per-section HIP events behind `roofline` / `section_ms` are recorded in a
+          THIRD run of the same K steps (primed; every 8th iteration), because a profiled iteration costs ~60 us of event
+          records and pipeline bubbles -- 3.4 % of a 20-step window (profiles/r3_trace_20step_gaps.txt).
 
 multi-GPU: `python bench.py --gpus N` launches N ranks itself (torch.distributed.run, one process per GPU, RCCL)
           when it is not already running under a launcher; under `python -m torch.distributed.run ... bench.py
@@ -299,16 +301,19 @@ def main():
     run(new_fitter(), scaled_schedule(n_warm))
     sched = scaled_schedule(args.steps)
 
-    def timed(primed):
+    def timed(primed, sections=False):
         """EXACTLY args.steps iterations of a fresh fit between two synchronisation points"""
         fitter = new_fitter()
         base = fitter.fitter if use_dist else fitter
+        if not use_dist:
+            base.prepare_schedule()                                  # argument blocks of the four stages (host-side, once per fit)
         base.e.reset_raster_cache()                                  # a new sequence: no depth bounds from the warm-up fit
         if primed:
             base.evaluate(W[1][:6], float(W[1][6]), 1, want=())      # silhouette of the initial state: primes the depth-bound cache
-        # HIP events on the launch stream inside the timed region, on every 8th iteration (an event record costs ~5 us
-        # of stream time; all sections of every iteration would slow the measured loop by several percent)
-        base.e.profile_begin(args.steps, PROFILE_STRIDE)
+        if sections:
+            # HIP events on the launch stream around the sections of every 8th iteration (an event record costs ~5 us of
+            # stream time and stalls the launch pipeline: kept out of the two regions the rates are quoted on)
+            base.e.profile_begin(args.steps, PROFILE_STRIDE)
         stage_events = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         sync()
         t0 = time.perf_counter()
@@ -321,13 +326,15 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         stage_seconds = [stage_events[i].elapsed_time(stage_events[i + 1]) * 1e-3 for i in range(4)]
-        return dict(elapsed=elapsed, t_issued=t_issued, stage_seconds=stage_seconds, sections=base.e.profile_end(),
+        return dict(elapsed=elapsed, t_issued=t_issued, stage_seconds=stage_seconds, sections=base.e.profile_end() if sections else None,
                     status=base.e.status(), fitter=fitter, base=base)
 
-    cold = timed(primed=False)          # -> value
-    primed = timed(primed=True)         # -> value_primed
-    elapsed, t_issued, stage_seconds, sections, status = (cold[k] for k in ("elapsed", "t_issued", "stage_seconds", "sections", "status"))
-    status |= primed["status"]
+    cold = timed(primed=False)                       # -> value
+    primed = timed(primed=True)                      # -> value_primed
+    profiled = timed(primed=True, sections=True)     # -> section_ms / roofline (not a quoted rate)
+    elapsed, t_issued, stage_seconds, status = (cold[k] for k in ("elapsed", "t_issued", "stage_seconds", "status"))
+    sections = profiled["sections"]
+    status |= primed["status"] | profiled["status"]
     fitter, base = cold["fitter"], cold["base"]
     final_losses = (fitter.global_losses() if use_dist else base.losses).cpu().numpy().tolist()
     import hashlib
@@ -390,7 +397,9 @@ def main():
                          # whole iteration, whole job: SURVEY.md section 8d's byte formula over the measured step, against N x peak
                          "iteration": {"algorithmic_bytes": iter_bytes, "achieved": iter_bytes / (ms_per_step * 1e-3) / 1e9,
                                        "frac": iter_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)}},
-            "section_ms": sec_ms, "final_losses": dict(zip(eng.LOSS_NAMES, final_losses)), "status_bits": status,
+            "section_ms": sec_ms, "section_ms_source": "third run of the same steps (primed, HIP events on every %dth iteration): %.1f it/s with the events in"
+                                                     % (PROFILE_STRIDE, args.steps / profiled["elapsed"]),
+            "final_losses": dict(zip(eng.LOSS_NAMES, final_losses)), "status_bits": status,
             "final_state_sha256": state_sha, "kernel_source_sha": kernel_source_sha(),
         }
         if not args.no_cpu_baseline and world == 1:

@@ -108,6 +108,7 @@ class FusedFitter:
         self.losses = torch.zeros(eng.NUM_LOSS_TERMS, **f32)
         self.step_count = 0
         self.halo_prev = self.halo_next = None
+        self._plan = None
         self.use_joint_limits = False          # opt-in (enable_joint_limits): the reference's term is commented out
 
     def enable_joint_limits(self, min_values=None, max_values=None):
@@ -118,6 +119,7 @@ class FusedFitter:
             min_values, max_values = model_io.joint_limit_table()
         self.e.set_joint_limits(min_values, max_values)
         self.use_joint_limits = True
+        self._plan = None                      # argument blocks built so far carry w_limit = 0
 
     # ---- stage control (optimize_to_joints.py:96-110) --------------------------------------------------
     def trainable(self, stage_id):
@@ -133,7 +135,8 @@ class FusedFitter:
         first Adam step of a stage takes the moments as zero (smalfit_adam_args.step == 0)."""
         self.step_count = 0
         self.stage_id = stage_id
-        self._plan = None
+        # (the argument blocks of _stage_plan depend on weights / stage / trainable set / halo buffers only, not on the
+        # optimiser's step count: they survive a stage change, see prepare_schedule)
 
     def _segments(self, names):
         """contiguous [start, end) runs of the flat buffer covering the trainable tensors"""
@@ -189,7 +192,7 @@ class FusedFitter:
                None if self.halo_next is None else self.halo_next.data_ptr())
         plans = self._plan if isinstance(getattr(self, "_plan", None), dict) else {}
         if key not in plans:
-            if len(plans) > 4:
+            if len(plans) > 8:
                 plans.clear()
             fa, _, _, keep = self._fit_args(weights, w_temp, stage_id, names)
             plans[key] = (fa, self._adam_args(names, lr), keep)
@@ -197,6 +200,14 @@ class FusedFitter:
         fa, aa, _ = plans[key]
         aa.step = self.step_count
         return fa, aa
+
+    def prepare_schedule(self, opt_weights=None):
+        """builds the argument blocks of every stage of the schedule up front (config.OPT_WEIGHTS by default), so that a stage
+        change inside the loop is a dictionary lookup and one library call instead of ~100 us of ctypes marshalling while
+        the GPU idles.  Optional: run_iterations builds what it does not find."""
+        W = np.array(config.OPT_WEIGHTS if opt_weights is None else opt_weights).T
+        for stage_id, w in enumerate(W):
+            self._stage_plan(w[:6], float(w[6]), float(w[8]), stage_id, self.trainable(stage_id))
 
     def run_iterations(self, weights, w_temp, lr, stage_id, iterations):
         """`iterations` epochs of the reference loop in ONE library call (smalfit_fit_run): evaluation + analytic
@@ -223,7 +234,7 @@ class FusedFitter:
                None if self.halo_next is None else self.halo_next.data_ptr())
         plans = self._plan if isinstance(getattr(self, "_plan", None), dict) else {}
         if key not in plans:
-            if len(plans) > 4:
+            if len(plans) > 8:
                 plans.clear()
             fa, _, _, keep = self._fit_args(weights, w_temp, stage_id, names)
             plans[key] = (fa, self._adam_args(local, lr), keep)

@@ -534,3 +534,67 @@ def case_fit_family0_512(golden, M=2, S=512, window=2, stage=2, seed=43):
     for k in names:
         out["grad_%s_rel" % k] = rel(grads[k].cpu().numpy(), grads_o[k].numpy())
     return out
+
+
+def case_config5_fit(family, M=2, S=512, window=2, iters=4, seed=47):
+    """BASELINE config 5 as a fit, one shape family at a time (mixed families are independent fitters: replicas, no collective):
+    512 x 512 silhouettes, limb scales on -- family 1 with the unity-style 26-dim prior and shared scales, every other family
+    with its 20-dim SMAL cluster prior and per-frame (N,6) limb scales trained without a regulariser (reference
+    smal_fitter.py:48-72, optimize_to_joints.py:108-109) -- `iters` stage-2 iterations of FusedFitter (losses + analytic
+    gradients + Adam) against the oracle loop from the same start."""
+    from smalify_amd import fitter as fit
+    W = np.array(cfg.OPT_WEIGHTS).T
+    stage = 2
+    weights, w_temp, lr = W[stage][:6].copy(), float(W[stage][6]), float(W[stage][8])
+    unity = family == 1
+    dd, data, sym = synthetic.synthetic_smal_dicts(seed=0)
+    mdf = model_io.prepare_model(dd, data, sym, family)
+    om = so.OracleModel(mdf)
+    dm = eng.DeviceModel(mdf)
+    e = eng.Engine(dm, M, S)
+    pp = synthetic.synthetic_pose_prior()
+    sp = synthetic.synthetic_shape_prior() if unity else model_io.family_shape_prior(data, family)
+    e.set_pose_prior(*pp)
+    e.set_shape_prior(*sp)
+    gt = random_pose(M, seed, z=1.6)
+    cur = random_pose(M, seed, z=1.6)
+    rs = np.random.RandomState(seed + 7 + family)
+    cur["global_rotation"] += (0.04 * rs.randn(M, 3)).astype(np.float32)
+    cur["joint_rotations"] += (0.06 * rs.randn(M, 34, 3)).astype(np.float32)
+    cur["trans"] += (0.02 * rs.randn(M, 3)).astype(np.float32)
+    if not unity:
+        cur["log_beta_scales"] = (0.1 * rs.randn(M, 6)).astype(np.float32)             # per-frame limb scales
+        gt_ls = np.tile(gt["log_beta_scales"], (M, 1))
+    else:
+        gt_ls = np.tile(gt["log_beta_scales"], (M, 1))
+    with torch.no_grad():
+        theta = np.concatenate([gt["global_rotation"][:, None], gt["joint_rotations"]], 1)
+        vo, jo, _, _ = so.smal_forward(om, torch.from_numpy(np.tile(gt["betas"], (M, 1))).double(), torch.from_numpy(theta).double(),
+                                       torch.from_numpy(gt_ls).double())
+        t = torch.from_numpy(gt["trans"]).double()[:, None]
+        tj = so.project_points((jo + t)[:, so.CANONICAL], S).numpy() + rs.randn(M, 25, 2)
+        tsil = (so.soft_silhouette(vo + t, om.faces, S) > 0.5).double().numpy()
+    vis = (rs.rand(M, 25) < 0.85).astype(np.float32)
+    prob = so.FitProblem(om, S, tj, vis, tsil, pp[0], pp[1], pp[2], sp[0], sp[1], window, use_unity_prior=unity)
+    names = so.trainable_names(stage)
+    params = {k: torch.from_numpy(v).double() for k, v in cur.items()}
+    opt = so.Adam(so.PARAM_ORDER, lr=lr)
+    hist_o = []
+    for _ in range(iters):
+        total, sums, grads = so.loss_and_grads(prob, params, weights, w_temp, names)
+        opt.step(params, grads)
+        hist_o.append(float(total))
+    f = fit.FusedFitter(e, tj.astype(np.float32), vis, tsil.astype(np.float32), window, unity, cur["betas"],
+                        cur["log_beta_scales"] if unity else None)
+    for k in ("global_rotation", "joint_rotations", "trans") + (() if unity else ("log_beta_scales",)):
+        f.p[k].copy_(dev(cur[k]).reshape(f.p[k].shape))
+    f.begin_stage(stage)
+    hist = []
+    for _ in range(iters):
+        f.step(weights, w_temp, lr, stage)
+        hist.append(float(f.losses.double().sum().item()))
+    out = {"status": e.status(), "family": family, "per_frame_scales": not unity, "sil_oracle": sums.get("sil_reproj", 0.0),
+           "loss_rel_max": float(np.max(np.abs(np.array(hist) - np.array(hist_o)) / np.abs(np.array(hist_o))))}
+    for k in ("betas", "log_beta_scales", "global_rotation", "joint_rotations", "trans"):
+        out["param_%s_rel" % k] = rel(f.p[k].cpu().numpy().reshape(params[k].shape), params[k].numpy())
+    return out

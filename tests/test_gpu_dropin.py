@@ -330,3 +330,49 @@ def test_fit_sequence_runs_the_schedule_and_writes_the_final_files(golden, md, t
         panel = rows[:, 3 * S:4 * S, 0].astype(np.float64)
         assert np.abs(panel - expect[i]).max() <= 1.0, np.abs(panel - expect[i]).max()
         assert (panel > 250).mean() > 0.5
+
+
+def test_joint_limits_stay_with_the_fitter_that_asked_for_them(golden, md):
+    """engines are shared between fitters of one model and image size (runtime.get_engine): a fitter that enables the joint-limit
+    term must not switch it on for the next default fitter -- the reference has the term commented out while its weight table
+    says 100 (smal_fitter.py:146-151, config.py:68)"""
+    from smalify_amd.smal_fitter.smal_fitter import SMALFitter
+    data, N, S = _data(golden)
+    pri = dict(model_data=md, pose_prior_data=(golden["pose_prec"], golden["pose_mean"], golden["pose_mask"]),
+               shape_prior_data=(golden["unity_prec"], golden["unity_mean"]))
+    w = [float(x) for x in golden["g6_w1"]]
+    w[4] = 100.0                                        # the weight table's w_limit
+    rs = np.random.RandomState(3)
+    jr = torch.from_numpy((0.6 * rs.randn(N, 34, 3)).astype(np.float32)).cuda()      # well outside the limits
+
+    def total(fitter):
+        with torch.no_grad():
+            fitter.joint_rotations.copy_(jr)
+        loss, objs = fitter.forward(list(range(N)), w, 1)
+        return float(loss), objs
+
+    plain0, objs0 = total(SMALFitter("cuda", data, N, 1, True, **pri))
+    limited, objs1 = total(SMALFitter("cuda", data, N, 1, True, enable_joint_limits=True, **pri))
+    plain1, objs2 = total(SMALFitter("cuda", data, N, 1, True, **pri))               # same engine, after the limited fitter
+    assert "limit" in objs1 and float(objs1["limit"]) > 0.0 and limited > plain0
+    assert "limit" not in objs0 and "limit" not in objs2
+    assert plain1 == plain0
+
+
+def test_fit_args_of_another_header_are_refused(md):
+    """smalfit_fit_args.struct_size (ABI v3): a struct laid out by another version of smalfit.h is an error, not a misread"""
+    import ctypes as C
+    from smalify_amd import engine as eng, synthetic
+    e = eng.Engine(eng.DeviceModel(md), 2, 64)
+    e.set_pose_prior(*synthetic.synthetic_pose_prior())
+    e.set_shape_prior(*synthetic.synthetic_shape_prior())
+    z = lambda *s: torch.zeros(*s, device="cuda")  # noqa: E731
+    a, _, _, keep = e.build_fit_args(betas=z(20), log_beta_scales=z(6), global_rotation=z(2, 3), joint_rotations=z(2, 34, 3), trans=z(2, 3),
+                                     target_joints=z(2, 25, 2), target_visibility=z(2, 25), target_sil=None, weights=(1, 0, 0, 0, 0, 0),
+                                     w_temp=0.0, window=2)
+    assert a.struct_size == C.sizeof(type(a))
+    assert e.lib.smalfit_fit_eval(e.handle, eng._stream(), C.byref(a)) == 0
+    a.struct_size -= 8
+    assert e.lib.smalfit_fit_eval(e.handle, eng._stream(), C.byref(a)) != 0
+    assert b"struct_size" in e.lib.smalfit_last_error()
+    assert e.lib.smalfit_version() == eng._lib.ABI_VERSION

@@ -179,6 +179,21 @@ def test_fit_non_unity_family_with_per_frame_limb_scales_at_512(golden):
             assert v < 2e-3, (k, v, m)
 
 
+@pytest.mark.parametrize("family", [0, 1, 2, 3])
+def test_config5_short_fit_every_shape_family_at_512(family):
+    """BASELINE config 5 (mixed shape-family batch, 512 x 512, limb scales on) is a set of independent fitters, one per family:
+    each family's fitter -- cat / canine / equine / bovine; the unity-style prior with shared scales for family 1, the SMAL
+    cluster prior with per-frame trained limb scales for the others -- follows the oracle loop for four stage-2 iterations
+    within north_star's 1e-4"""
+    m = pc.case_config5_fit(family)
+    print("config 5, family %d: %s" % (family, {k: ("%.2e" % v if isinstance(v, float) else v) for k, v in m.items()}))
+    assert m["status"] == 0 and m["sil_oracle"] > 0.0
+    assert m["loss_rel_max"] < 1e-4, m
+    for k, v in m.items():
+        if k.startswith("param_"):
+            assert v < 1e-4, (k, v, m)
+
+
 def test_graph_replay_gives_the_same_bits_as_individual_launches():
     """smalfit_engine_set_graph: one captured iteration replayed per step (Adam's step count in a device counter, bias
     corrections formed on the device) ends in the same parameters and losses as the launch-by-launch loop"""
