@@ -274,3 +274,38 @@ def test_full_schedule_fixture_is_current():
     np.testing.assert_allclose(trace, z["trace"][:len(trace)], rtol=1e-9)
     # the stored per-term sums are those of the last evaluation
     np.testing.assert_allclose(sum(float(z[k]) for k in z.files if k.startswith("sum_")), z["trace"][-1], rtol=1e-9)
+
+
+def test_config2_fixtures_are_current():
+    """tests/golden/oracle_config2_{f64,f32,heads}.npz (BASELINE config 2's shape: 8 frames, 256 x 256, WINDOW_SIZE 8, the full
+    150/400/600/800 schedule; hours of oracle CPU time, tests/golden/make_oracle_config2.py) belong to the problem
+    tests/config2_case.py builds today and to today's oracle: same inputs bit for bit, and the head of the float64 loop --
+    three keypoint iterations of stage 0, then the first silhouette iteration from the stored stage-1 start -- reproduces the
+    stored trace."""
+    import torch
+    from tests import config2_case as c2
+    from oracle import smal_oracle as so
+    from smalify_amd import config as cfg
+    f64 = c2.load_fixture("f64")
+    assert f64 is not None and f64["complete"], "run tests/golden/make_oracle_config2.py f64"
+    md, tg = c2.targets()
+    start = c2.initial_params()
+    fp = c2.fingerprint(tg, start)
+    assert f64["fingerprint"] == fp, "the float64 fixture belongs to other inputs: regenerate it"
+    assert c2.fingerprint(f64["targets"], start) == fp            # the targets that travel with the fixture are these
+    assert f64["schedule"] == c2.SCHEDULE and f64["trace"].shape == (sum(c2.SCHEDULE), len(c2.TERMS))
+    f32 = c2.load_fixture("f32")
+    assert f32 is not None and f32["complete"] and f32["fingerprint"] == fp, "run tests/golden/make_oracle_config2.py f32"
+    heads = np.load(c2.fixture_path("heads"), allow_pickle=False)
+    assert str(heads["fingerprint"]) == fp and all("stage%d_f32_trace" % s in heads.files for s in range(4)), \
+        "run tests/golden/make_oracle_config2.py heads"
+    prob = c2.problem(md, tg, torch.float64)
+    trace, stage_start, _ = c2.oracle_schedule(prob, start, torch.float64, schedule=(3, 0, 0, 0))
+    np.testing.assert_allclose(trace, f64["trace"][:3], rtol=1e-9, atol=1e-12)
+    W = np.array(cfg.OPT_WEIGHTS).T
+    params = {k: torch.from_numpy(v) for k, v in f64["stage_start"][1].items()}
+    total, sums, _ = so.loss_and_grads(prob, params, W[1][:6].copy(), float(W[1][6]), so.trainable_names(1))
+    ref = f64["trace"][c2.SCHEDULE[0]]
+    np.testing.assert_allclose([sums.get(k, 0.0) for k in c2.TERMS], ref, rtol=1e-9, atol=1e-12)
+    # the float32 run is a float32 run: it leaves the float64 trace, but not by much in the first iterations
+    assert 0.0 < abs(f32["trace"][0].sum() - f64["trace"][0].sum()) / f64["trace"][0].sum() < 1e-5

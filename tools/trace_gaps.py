@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""developer helper (GPU box): kernel-by-kernel timeline (start, duration, gap before) of iterations 0, 1, 2 and 8 of the COLD timed
+run of `bench.py --steps STEPS` from a rocprofv3 --kernel-trace CSV -- shows where a window loses time BETWEEN kernels (host-bound
+stage 0, event records).  usage: python tools/trace_gaps.py KERNEL_TRACE.csv STEPS"""
 import csv, sys
 path, steps = sys.argv[1], int(sys.argv[2])
 rows = list(csv.DictReader(open(path)))
@@ -9,7 +13,7 @@ for r in rows:
     cur.append((name, int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
     if name.startswith("adam_segments"):
         its.append(cur); cur = []
-sel = its[-2 * steps:-steps]
+sel = its[-3 * steps:-2 * steps]          # the cold run (bench.py ends with cold, primed, profiled)
 t0 = sel[0][0][1]
 prev_end = None
 for i in (0, 1, 2, 8):

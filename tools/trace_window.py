@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """developer helper (GPU box): per-iteration kernel durations of a bench window from a rocprofv3 --kernel-trace CSV.
-usage: python tools/trace_window.py KERNEL_TRACE.csv STEPS [which]    which = cold (default) | primed
-An iteration ends with adam_segments_kernel; the last 2*STEPS iterations of the trace are the cold and the primed timed runs."""
+usage: python tools/trace_window.py KERNEL_TRACE.csv STEPS [which]    which = cold (default) | primed | profiled
+An iteration ends with adam_segments_kernel; the last 3*STEPS iterations of the trace are the cold, the primed and the profiled runs."""
 import csv
 import sys
 
@@ -18,7 +18,8 @@ for r in rows:
     if name.startswith("adam_segments"):
         its.append(cur)
         cur = []
-sel = its[-2 * steps:-steps] if which == "cold" else its[-steps:]
+# bench.py times three runs of STEPS iterations at the end of the process: cold, primed, profiled (section events)
+sel = {"cold": its[-3 * steps:-2 * steps], "primed": its[-2 * steps:-steps], "profiled": its[-steps:]}[which]
 cols = ["lbs_head", "skin_mfma", "face_bbox", "raster_sweep", "raster_resolve", "raster_band", "raster_select", "raster_bwd", "vertex_bwd", "lbs_bwd_mid", "chain_bwd", "assemble", "adam_segments"]
 print("%3s %8s | " % ("it", "wall") + " ".join("%7s" % c.replace("raster_", "")[:7] for c in cols))
 for i, it in enumerate(sel):
