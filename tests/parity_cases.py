@@ -536,7 +536,7 @@ def case_fit_family0_512(golden, M=2, S=512, window=2, stage=2, seed=43):
     return out
 
 
-def case_config5_fit(family, M=2, S=512, window=2, iters=4, seed=47):
+def case_config5_fit(family, M=2, S=512, window=2, iters=2, seed=47, z=1.9):
     """BASELINE config 5 as a fit, one shape family at a time (mixed families are independent fitters: replicas, no collective):
     512 x 512 silhouettes, limb scales on -- family 1 with the unity-style 26-dim prior and shared scales, every other family
     with its 20-dim SMAL cluster prior and per-frame (N,6) limb scales trained without a regulariser (reference
@@ -548,7 +548,11 @@ def case_config5_fit(family, M=2, S=512, window=2, iters=4, seed=47):
     weights, w_temp, lr = W[stage][:6].copy(), float(W[stage][6]), float(W[stage][8])
     unity = family == 1
     dd, data, sym = synthetic.synthetic_smal_dicts(seed=0)
-    mdf = model_io.prepare_model(dd, data, sym, family)
+    # the synthetic stand-in's shape basis is not mirror-symmetric: adding the cluster mean of family 2 or 3 leaves the template
+    # with unequal left / right vertex counts, where the reference stops (smal_basics.py:32-35) and so does prepare_model.  Those
+    # two families are exercised through THEIR cluster priors (what distinguishes the fitters of a mixed batch on the fitting
+    # path) on the family-0 mesh; the family-dependent template itself is covered by families 0 and 1.
+    mdf = model_io.prepare_model(dd, data, sym, family if family in (0, 1) else 0)
     om = so.OracleModel(mdf)
     dm = eng.DeviceModel(mdf)
     e = eng.Engine(dm, M, S)
@@ -556,8 +560,8 @@ def case_config5_fit(family, M=2, S=512, window=2, iters=4, seed=47):
     sp = synthetic.synthetic_shape_prior() if unity else model_io.family_shape_prior(data, family)
     e.set_pose_prior(*pp)
     e.set_shape_prior(*sp)
-    gt = random_pose(M, seed, z=1.6)
-    cur = random_pose(M, seed, z=1.6)
+    gt = random_pose(M, seed, z=z)
+    cur = random_pose(M, seed, z=z)
     rs = np.random.RandomState(seed + 7 + family)
     cur["global_rotation"] += (0.04 * rs.randn(M, 3)).astype(np.float32)
     cur["joint_rotations"] += (0.06 * rs.randn(M, 34, 3)).astype(np.float32)

@@ -183,8 +183,8 @@ def test_fit_non_unity_family_with_per_frame_limb_scales_at_512(golden):
 def test_config5_short_fit_every_shape_family_at_512(family):
     """BASELINE config 5 (mixed shape-family batch, 512 x 512, limb scales on) is a set of independent fitters, one per family:
     each family's fitter -- cat / canine / equine / bovine; the unity-style prior with shared scales for family 1, the SMAL
-    cluster prior with per-frame trained limb scales for the others -- follows the oracle loop for four stage-2 iterations
-    within north_star's 1e-4"""
+    cluster prior with per-frame trained limb scales for the others -- follows the oracle loop (losses, analytic gradients, Adam) for two stage-2
+    iterations within north_star's 1e-4 (the oracle needs ~10 s per 512 x 512 iteration: more would dominate the suite)"""
     m = pc.case_config5_fit(family)
     print("config 5, family %d: %s" % (family, {k: ("%.2e" % v if isinstance(v, float) else v) for k, v in m.items()}))
     assert m["status"] == 0 and m["sil_oracle"] > 0.0

@@ -5,7 +5,7 @@
 tag=${1:-rX}
 cd $GRAFT_REPO_ROOT
 out=gpurun_out
-timeout 500 python -m pytest tests -q -m gpu -x 2>&1 | tee $out/${tag}_gpu_tests.log | tail -25
+timeout 600 python -m pytest tests -q -m gpu 2>&1 | tee $out/${tag}_gpu_tests.log | tail -25
 timeout 240 python bench.py > $out/${tag}_bench_default.json 2> $out/${tag}_bench_default.err
 timeout 60 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/${tag}_bench_20_driver_args.json 2>> $out/${tag}_bench_default.err
 timeout 90 python bench.py --steps 1950 --no-cpu-baseline > $out/${tag}_bench_1950_survey.json 2>> $out/${tag}_bench_default.err
