@@ -376,3 +376,38 @@ def test_fit_args_of_another_header_are_refused(md):
     assert e.lib.smalfit_fit_eval(e.handle, eng._stream(), C.byref(a)) != 0
     assert b"struct_size" in e.lib.smalfit_last_error()
     assert e.lib.smalfit_version() == eng._lib.ABI_VERSION
+
+
+def test_loaders_feed_device_resident_targets(md, golden, tmp_path):
+    """SURVEY section 8f row 2, GPU side: a dataset in BADJA's on-disk format (PNG frames + half-resolution segmentation PNGs +
+    the joint-annotation JSON) and one in StanfordExtra's (RLE masks) go through the cv2 / imageio / pycocotools-free loaders
+    and from there into device-resident targets -- bytes where the crop is an exact multiple of 1/255, float32 where the
+    reference's bilinear resize of BADJA masks leaves other values -- and a short fit runs on them."""
+    from tests.test_data_loader_cpu import _write_badja
+    from smalify_amd import engine as eng, fitter as fit
+    from smalify_amd.smal_fitter import data_loader as dl
+    from smalify_amd.smal_fitter.optimize_to_joints import fit_sequence, write_png
+    import json
+    root = str(tmp_path / "BADJA")
+    _write_badja(root)
+    (rgb, sil, joints, vis), names = dl.load_badja_sequence(root, "synth", 64, image_range=range(0, 3))
+    pri = ((golden["pose_prec"], golden["pose_mean"], golden["pose_mask"]), (golden["unity_prec"], golden["unity_mean"]))
+    f = fit_sequence((rgb, sil, joints, vis), names, md, pri[0], pri[1], output_dir=None, window_size=2, iters_scale=0.02)
+    assert f.e.status() == 0 and np.isfinite(f.losses.cpu().numpy()).all()
+    # whatever the storage, the kernels see exactly the loader's silhouettes
+    assert torch.equal(f.target_sil_float().cpu(), sil.reshape(3, 64, 64))
+    exact = bool((torch.round(sil * 255.0) / 255.0 == sil).all())
+    assert (f.target_sil.dtype == torch.uint8) == exact
+    # StanfordExtra: RLE mask -> nearest-neighbour crop: binary, hence bytes on the device
+    sroot = str(tmp_path / "StanfordExtra")
+    os.makedirs(os.path.join(sroot, "sample_imgs", "n0-dog"))
+    rs = np.random.RandomState(3)
+    write_png(os.path.join(sroot, "sample_imgs", "n0-dog", "a.png"), (rs.rand(50, 70, 3) * 255).astype(np.uint8))
+    mask = np.zeros((50, 70), np.uint8); mask[10:40, 20:60] = 1
+    sj = np.concatenate([rs.rand(24, 2) * [70, 50], (rs.rand(24, 1) < 0.8)], 1)
+    with open(os.path.join(sroot, "StanfordExtra_sample.json"), "w") as fh:
+        json.dump([{"img_path": "n0-dog/a.png", "img_height": 50, "img_width": 70, "seg": dl.encode_rle(mask), "joints": sj.tolist()}], fh)
+    (rgb1, sil1, j1, v1), n1 = dl.load_stanford_sequence(sroot, "n0-dog/a.png", 64)
+    f1 = fit_sequence((rgb1, sil1, j1, v1), n1, md, pri[0], pri[1], output_dir=None, window_size=1, iters_scale=0.02)
+    assert f1.e.status() == 0 and f1.target_sil.dtype == torch.uint8
+    assert torch.equal(f1.target_sil_float().cpu(), sil1.reshape(1, 64, 64))
