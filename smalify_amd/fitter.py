@@ -186,7 +186,10 @@ class FusedFitter:
         self.step_count = a.step
 
     def _stage_plan(self, weights, w_temp, lr, stage_id, names):
-        """argument blocks of the stage's iterations, rebuilt only when something they depend on changes"""
+        """argument blocks of the stage's iterations, rebuilt only when something they depend on changes.  The halo buffers
+        enter the key by ADDRESS (the block holds raw device pointers): ShardedFitter hands out views of one persistent
+        gather buffer, so the key is stable across iterations; a caller that allocates fresh halo tensors every step gets a
+        fresh block every step -- correct, but it pays the ~100 us of marshalling each time (reuse the buffers instead)."""
         key = (tuple(float(w) for w in weights), float(w_temp), float(lr), stage_id, tuple(names),
                None if self.halo_prev is None else self.halo_prev.data_ptr(),
                None if self.halo_next is None else self.halo_next.data_ptr())
