@@ -7,6 +7,7 @@ from a group instead of failing the pass.  Writes gpurun_out/<tag>/pmc_summary.j
 average per launch (summed over the dimension rows of one dispatch).
 
 usage: python tools/pmc_sq.py TAG [bench args...]        (default bench args: --steps 39 --warmup 4 --no-cpu-baseline)
+       PMC_SCRIPT="tools/raster_probe.py" python tools/pmc_sq.py TAG      (another script of the repo instead of bench.py)
 """
 import collections
 import csv
@@ -45,7 +46,7 @@ def main():
         names = [c for c in group if (c + " ") in listing or (c + "\n") in listing or ("Name: " + c) in listing or c in listing] or group
         d = os.path.join(out, "g%d" % gi)
         cmd = ["rocprofv3", "--pmc"] + names + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
-                                                sys.executable, os.path.join(ROOT, "bench.py")] + bench_args
+                                                sys.executable] + (os.environ["PMC_SCRIPT"].split() if os.environ.get("PMC_SCRIPT") else [os.path.join(ROOT, "bench.py")] + bench_args)
         r = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp", env=env)
         open(os.path.join(out, "g%d.log" % gi), "w").write(" ".join(cmd) + "\n" + r.stdout[-2000:] + "\n" + r.stderr[-4000:])
         agg = collections.defaultdict(lambda: collections.defaultdict(float))

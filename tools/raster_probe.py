@@ -14,7 +14,7 @@ def main():
     e.set_pose_prior(*synthetic.synthetic_pose_prior())
     lib = _lib.load()
     W = np.array(config.OPT_WEIGHTS).T
-    for scene in ("survey", "crop"):
+    for scene in os.environ.get("PROBE_SCENES", "survey,crop").split(","):
         gt, tj, vis, tsil, sp = bench.build_problem(e, torch, scene)
         e.set_shape_prior(*sp)
         f = fit.FusedFitter(e, tj, vis, tsil, 8, True, sp[1][:20], sp[1][20:26])
