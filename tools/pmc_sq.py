@@ -63,7 +63,14 @@ def main():
             e = summary.setdefault(k, {"launches": n})
             for c, v in cs.items():
                 e[c] = v / n
-    json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    sys.path.insert(0, ROOT)
+    import bench                                                   # the stamp bench.py checks before quoting `traffic` from this file
+    what = os.environ.get("PMC_SCRIPT") or ("bench.py " + " ".join(bench_args))
+    stamped = dict(summary, _note="rocprofv3 --pmc passes (one group of counters per run, --kernel-trace only) of `" + what + "`, made by tools/pmc_sq.py; "
+                   "per kernel: average per launch; FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE reports half of a wide coalesced read on gfx950, "
+                   "MI355X_MICROARCH.md); kernel_source_sha = bench.kernel_source_sha() of the sources measured",
+                   kernel_source_sha=bench.kernel_source_sha())
+    json.dump(stamped, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
     for k in sorted(summary, key=lambda k: -summary[k].get("SQ_WAVE_CYCLES", 0))[:8]:
         print(k, json.dumps({c: round(v, 1) for c, v in summary[k].items()}))
 
