@@ -113,6 +113,12 @@ def test_full_schedule_end_state_within_the_float32_yardstick(case):
         ends[stage] = ({k: f.p[k].cpu().numpy().astype(np.float64) for k in c2.PARAMS}, f.losses.cpu().numpy().astype(np.float64))
     assert case["e"].status() == 0
     checked = 0
+    # The yardstick of a tensor at a stage end is the LARGEST deviation the float32 oracle has shown for it at any stage end so
+    # far, as in the loss-trace test above: drift does not un-happen.  (One tensor of the float32 run can come back towards the
+    # float64 run by chance -- its translation is 2.1e-2 off after stage 1 and 5.7e-3 after stage 2 -- and a bound made of that
+    # one lucky draw would fail a second float32 trajectory that is no worse than the first was a stage earlier.)
+    yard_max = {k: 0.0 for k in c2.PARAMS}
+    failures = []
     for stage in range(4):
         # the state at the END of stage s is the oracle's state at the START of stage s + 1 (or `final`)
         ref64 = f64["stage_start"].get(stage + 1) if stage < 3 else (f64["final"] or None)
@@ -122,8 +128,11 @@ def test_full_schedule_end_state_within_the_float32_yardstick(case):
         checked += 1
         for k in c2.PARAMS:
             hip, yard = _rel(ends[stage][0][k], ref64[k]), _rel(ref32[k], ref64[k])
-            print("config 2, end of stage %d, %-16s rel-L2: HIP vs f64 %.2e   f32 oracle vs f64 %.2e" % (stage, k, hip, yard))
-            assert hip <= DRIFT_FACTOR * yard + 1e-6, (stage, k, hip, yard)
+            yard_max[k] = max(yard_max[k], yard)
+            print("config 2, end of stage %d, %-16s rel-L2: HIP vs f64 %.2e   f32 oracle vs f64 %.2e (so far %.2e)" % (stage, k, hip, yard, yard_max[k]))
+            if not hip <= DRIFT_FACTOR * yard_max[k] + 1e-6:
+                failures.append((stage, k, hip, yard_max[k]))
+    assert not failures, failures
     if checked == 0:
         pytest.skip("fixtures incomplete: no stage end available yet")
     if f64["complete"] and f32["complete"]:
