@@ -349,7 +349,7 @@ def test_joint_limits_stay_with_the_fitter_that_asked_for_them(golden, md):
         with torch.no_grad():
             fitter.joint_rotations.copy_(jr)
         loss, objs = fitter.forward(list(range(N)), w, 1)
-        return float(loss), objs
+        return float(loss.detach()), objs
 
     plain0, objs0 = total(SMALFitter("cuda", data, N, 1, True, **pri))
     limited, objs1 = total(SMALFitter("cuda", data, N, 1, True, enable_joint_limits=True, **pri))
