@@ -1,9 +1,9 @@
 """Counterpart of reference smal_fitter/utils.py (crop_to_silhouette) without cv2.
 
 cv2.resize is restated for the two modes the reference uses on float images:
-  INTER_NEAREST  source index = floor(dst_index * src_size / dst_size)          (OpenCV's legacy nearest, no half-pixel shift)
-  INTER_LINEAR   source coordinate = (dst_index + 0.5) * src_size / dst_size - 0.5, bilinear, border replicated,
-                 interpolation weights rounded to float32 as in OpenCV's resizeLinear for CV_64F
+  INTER_NEAREST  source index = floor(dst_index * (1 / (dst_size / src_size)))  (OpenCV's legacy nearest, no half-pixel shift)
+  INTER_LINEAR   source coordinate = (float32)((dst_index + 0.5) * (1 / (dst_size / src_size)) - 0.5), bilinear, border replicated,
+                 float32 interpolation weights as in OpenCV's resize for CV_64F (opencv imgproc/src/resize.cpp: resizeNN, resize_)
 cv2 is not installed here, so these restatements are **parity unpinned** (SURVEY §8f row 2)."""
 from __future__ import annotations
 
@@ -11,26 +11,32 @@ import numpy as np
 
 
 def resize_nearest(img, out_h, out_w):
+    # OpenCV resizeNN: ifx = 1. / (dsize / ssize) in double (NOT ssize / dsize: the two differ in the last bit, which decides
+    # floor() where dst_index * ssize / dsize is an integer), sx = min(cvFloor(x * ifx), ssize - 1)
     h, w = img.shape[:2]
-    ys = np.minimum(np.floor(np.arange(out_h) * (h / float(out_h))).astype(np.int64), h - 1)
-    xs = np.minimum(np.floor(np.arange(out_w) * (w / float(out_w))).astype(np.int64), w - 1)
+    ify, ifx = 1.0 / (float(out_h) / float(h)), 1.0 / (float(out_w) / float(w))
+    ys = np.minimum(np.floor(np.arange(out_h) * ify).astype(np.int64), h - 1)
+    xs = np.minimum(np.floor(np.arange(out_w) * ifx).astype(np.int64), w - 1)
     return img[ys][:, xs]
 
 
 def _linear_taps(out_n, in_n):
-    scale = in_n / float(out_n)
-    f = (np.arange(out_n) + 0.5) * scale - 0.5
+    # OpenCV resize(INTER_LINEAR) coordinate set-up: scale = 1. / (dsize / ssize) in double, the source coordinate is rounded to
+    # float32 BEFORE it is split (fx = (float)((dx + 0.5) * scale - 0.5); sx = cvFloor(fx); fx -= sx), clamped at both borders
+    # (fx = 0, sx = 0 / ssize - 1), and the two weights are the float32 values 1.f - fx and fx
+    scale = 1.0 / (float(out_n) / float(in_n))
+    f = ((np.arange(out_n) + 0.5) * scale - 0.5).astype(np.float32)
     i0 = np.floor(f).astype(np.int64)
-    frac = f - i0
-    frac = np.where(i0 < 0, 0.0, frac)
+    frac = (f - i0.astype(np.float32)).astype(np.float32)
+    frac = np.where(i0 < 0, np.float32(0.0), frac)
     i0 = np.maximum(i0, 0)
     over = i0 >= in_n - 1
-    frac = np.where(over, 0.0, frac)
+    frac = np.where(over, np.float32(0.0), frac)
     i0 = np.where(over, in_n - 1, i0)
     i1 = np.minimum(i0 + 1, in_n - 1)
-    w1 = frac.astype(np.float32).astype(np.float64)
-    w0 = (1.0 - frac).astype(np.float32).astype(np.float64)
-    return i0, i1, w0, w1
+    w1 = frac.astype(np.float32)
+    w0 = (np.float32(1.0) - w1).astype(np.float32)
+    return i0, i1, w0.astype(np.float64), w1.astype(np.float64)
 
 
 def resize_linear(img, out_h, out_w):

@@ -27,6 +27,28 @@ def test_resize_follows_cv2_conventions():
     assert np.array_equal(resize_nearest(img, 5, 7), img) and np.allclose(resize_linear(img, 5, 7), img)
 
 
+def test_resize_agrees_with_an_independent_implementation_of_the_same_convention():
+    """cv2 is not installable here; torch's `interpolate` is a second, independent implementation of the conventions cv2.resize
+    follows for float images: bilinear with half-pixel centres and a clamped border, no antialiasing (INTER_LINEAR, up- and
+    down-scaling alike), and nearest = floor(dst * src / dst_size) (INTER_NEAREST, torch's legacy "nearest")."""
+    import torch
+    import torch.nn.functional as F
+    rs = np.random.RandomState(5)
+    # (source sizes prime to the target sizes: no destination index lands exactly on a source pixel boundary, where the last
+    # bit of the scale factor -- float32 in torch, double in OpenCV -- would decide the floor)
+    for (h, w), (oh, ow) in (((37, 53), (64, 64)), ((127, 79), (32, 48)), ((11, 13), (9, 31)), ((257, 307), (224, 224)), ((5, 7), (1, 1))):
+        img = rs.rand(h, w, 3)
+        t = torch.from_numpy(img).permute(2, 0, 1)[None]
+        lin = F.interpolate(t, size=(oh, ow), mode="bilinear", align_corners=False, antialias=False)[0].permute(1, 2, 0).numpy()
+        # (the restatement keeps OpenCV's float32 source coordinate and weights: half an ulp of a coordinate near 300 is 1.5e-5 of a pixel)
+        assert np.allclose(resize_linear(img, oh, ow), lin, rtol=0, atol=4e-5), (h, w, oh, ow)
+        near = F.interpolate(t, size=(oh, ow), mode="nearest")[0].permute(1, 2, 0).numpy()
+        assert np.array_equal(resize_nearest(img, oh, ow), near), (h, w, oh, ow)
+        mask = (rs.rand(h, w) > 0.5).astype(np.float64)                      # the silhouette path: 2-D, nearest
+        near2 = F.interpolate(torch.from_numpy(mask)[None, None], size=(oh, ow), mode="nearest")[0, 0].numpy()
+        assert np.array_equal(resize_nearest(mask, oh, ow), near2)
+
+
 def test_rle_known_answers_and_round_trip():
     # pycocotools: a full 2x2 mask is the runs [0, 4] -> "04"; an empty one is [4] -> "4"
     assert dl.encode_rle(np.ones((2, 2), np.uint8)) == "04" and dl.encode_rle(np.zeros((2, 2), np.uint8)) == "4"
