@@ -12,7 +12,8 @@ workload: synthetic BADJA-shape sequence, 64 frames, 256x256, WINDOW_SIZE 8, sha
 
 timing  : W untimed warm-up steps, then EXACTLY K steps between (barrier +) torch.cuda.synchronize() on both
           sides, nothing synchronising in between (per-stage times come from HIP events on the launch stream).
-          The warm-up is at least INTERNAL_WARMUP iterations whatever --warmup says (clocks, code objects, allocator);
+          The warm-up is at least INTERNAL_WARMUP iterations whatever --warmup says (clocks, code objects, allocator;
+          SMALFIT_BENCH_MIN_WARMUP overrides the floor for measurements of its effect);
           the JSON reports the real number.  `value` is COLD-HONEST: the rasteriser's per-pixel depth-bound cache is
           forgotten (smalfit_engine_reset_raster_cache) before the timed fit starts, so the fit pays its first exact
           K-nearest selection inside the timed region, exactly like a fit of a new sequence does.  `value_primed` is a
@@ -51,7 +52,7 @@ IMAGE_SIZE = 256
 WINDOW = 8
 SCHEDULE_ITERS = (150, 400, 600, 800)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-INTERNAL_WARMUP = 40           # minimum number of untimed iterations before the timed region
+INTERNAL_WARMUP = int(os.environ.get("SMALFIT_BENCH_MIN_WARMUP", "40"))           # minimum number of untimed iterations before the timed region
 PROFILE_STRIDE = 8
 PMC_SUMMARY = os.path.join("profiles", "r3_pmc_summary.json")
 
