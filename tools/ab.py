@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """developer helper (GPU box): A/B of library variants built with tools/build_variant.sh (or by hand into smalify_amd/_variants/).
-usage: python tools/ab.py [--steps K] [--reps R] NAME [NAME ...]      NAME = 'main' (smalify_amd/libsmalfit.so) or a variant name
+usage: python tools/ab.py [--steps K] [--reps R] [--scene survey|crop] NAME [NAME ...]      NAME = 'main' (smalify_amd/libsmalfit.so) or a variant name
 Runs bench.py per variant (SMALFIT_LIB) and prints value / value_primed / per-stage rates / the raster sections and the
 sha256 of the final parameters + losses -- equal hashes = bit-identical fits."""
 import json
@@ -10,12 +10,14 @@ import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 args = sys.argv[1:]
-steps, reps = 195, 1
+steps, reps, scene = 195, 1, "survey"
 while args and args[0].startswith("--"):
     if args[0] == "--steps":
         steps = int(args[1])
     elif args[0] == "--reps":
         reps = int(args[1])
+    elif args[0] == "--scene":
+        scene = args[1]
     args = args[2:]
 print("%-12s %8s %8s | %7s %7s %7s %7s | %6s %6s %6s %6s %6s %6s | %s" % ("variant", "cold", "primed", "st0", "st1", "st2", "st3", "sweep", "select", "bwd", "resolv", "lbsf", "lbsb", "state sha"))
 for name in args:
@@ -23,7 +25,7 @@ for name in args:
     if name != "main":
         env["SMALFIT_LIB"] = os.path.join(ROOT, "smalify_amd", "_variants", name + ".so")
     for _ in range(reps):
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--no-cpu-baseline"], env=env, capture_output=True, text=True)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--no-cpu-baseline", "--no-crop", "--scene", scene], env=env, capture_output=True, text=True)
         lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if out.returncode != 0 or not lines:
             print("%-12s FAILED rc=%d %s" % (name, out.returncode, out.stderr[-400:]))
