@@ -166,13 +166,24 @@ def load():
         lib = C.CDLL(LIB_PATH)
     except OSError as exc:
         raise SmalfitError("cannot load %s: %s" % (LIB_PATH, exc)) from exc
+    # the ABI version first: a stale library lacks newer entry points, and "rebuild" is the message the user needs
+    try:
+        lib.smalfit_version.restype = C.c_int
+        lib.smalfit_version.argtypes = []
+        version = lib.smalfit_version()
+    except AttributeError as exc:
+        raise SmalfitError("%s exports no smalfit_version(): not a libsmalfit of this source tree, rebuild it" % LIB_PATH) from exc
+    if version != ABI_VERSION:
+        raise SmalfitError("%s has ABI version %d, this binding mirrors version %d of include/smalfit.h: rebuild the library"
+                           % (LIB_PATH, version, ABI_VERSION))
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise SmalfitError("%s does not export %s although it reports ABI version %d: header / library mismatch, rebuild the library"
+                               % (LIB_PATH, name, version)) from exc
         fn.restype = res
         fn.argtypes = args
-    if lib.smalfit_version() != ABI_VERSION:
-        raise SmalfitError("%s has ABI version %d, this binding mirrors version %d of include/smalfit.h: rebuild the library"
-                           % (LIB_PATH, lib.smalfit_version(), ABI_VERSION))
     _lib = lib
     return lib
 

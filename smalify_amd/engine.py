@@ -88,6 +88,7 @@ class Engine:
               "smalfit_engine_create")
         self.handle = h
         self.device = torch.device("cuda", torch.cuda.current_device())
+        self.joint_limits_owner = None      # whoever set the engine's joint-limit table last (None: no table)
 
     def __del__(self):
         try:
@@ -118,12 +119,16 @@ class Engine:
     def clear_joint_limits(self):
         """back to the reference's behaviour: the w_limit column is ignored (its term is commented out upstream)"""
         check(self.lib.smalfit_engine_clear_joint_limits(self.handle), "smalfit_engine_clear_joint_limits")
+        self.joint_limits_owner = None
 
-    def set_joint_limits(self, min_values, max_values):
-        """(34,3) lower / upper limits of the joint rotations for the w_limit term (reference smal_fitter.py:76-79,146-151)"""
+    def set_joint_limits(self, min_values, max_values, owner=None):
+        """(34,3) lower / upper limits of the joint rotations for the w_limit term (reference smal_fitter.py:76-79,146-151).
+        The table is engine state; `owner` records whose it is, so that a fitter sharing the engine can tell that its table
+        was replaced or cleared behind its back and put it back (FusedFitter.assert_joint_limits)."""
         lo, hi = _host(min_values, np.float32).reshape(-1), _host(max_values, np.float32).reshape(-1)
         assert lo.shape == (102,) and hi.shape == (102,)
         check(self.lib.smalfit_engine_set_joint_limits(self.handle, lo.ctypes.data, hi.ctypes.data), "smalfit_engine_set_joint_limits")
+        self.joint_limits_owner = owner
 
     SECTIONS = ("lbs_fwd", "raster_sweep", "raster_select", "raster_bwd", "lbs_bwd", "raster_resolve", "raster_bbox")
 
@@ -518,6 +523,7 @@ class MeshTargets:
                                                    ff.ctypes.data, C.byref(h)), "smalfit_mesh_targets_create")
         self.handle = h
         self.device = torch.device("cuda", torch.cuda.current_device())
+        self.joint_limits_owner = None      # whoever set the engine's joint-limit table last (None: no table)
 
     def __len__(self):
         return len(self.verts_list)

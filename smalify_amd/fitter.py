@@ -117,9 +117,18 @@ class FusedFitter:
         (other fitters on the same engine keep passing w_limit = 0, like the reference)"""
         if min_values is None:
             min_values, max_values = model_io.joint_limit_table()
-        self.e.set_joint_limits(min_values, max_values)
+        self._joint_limits = (np.array(min_values, np.float32), np.array(max_values, np.float32))
         self.use_joint_limits = True
+        self.assert_joint_limits()
         self._plan = None                      # argument blocks built so far carry w_limit = 0
+
+    def assert_joint_limits(self):
+        """The limit table is state of the (possibly shared) engine: another fitter may have replaced or cleared it since this
+        one opted in (SMALFitter._engine clears it for fitters without limits).  Called before every evaluation of a fitter
+        that uses limits: puts this fitter's table back when the engine's is not this fitter's -- the w_limit term can never
+        silently drop out of the objective."""
+        if self.use_joint_limits and self.e.joint_limits_owner is not self:
+            self.e.set_joint_limits(self._joint_limits[0], self._joint_limits[1], owner=self)
 
     # ---- stage control (optimize_to_joints.py:96-110) --------------------------------------------------
     def trainable(self, stage_id):
@@ -168,6 +177,7 @@ class FusedFitter:
 
     def evaluate(self, weights, w_temp, stage_id, want=None, **outs):
         want = self.trainable(stage_id) if want is None else want
+        self.assert_joint_limits()
         a, _, _, _keep = self._fit_args(weights, w_temp, stage_id, want, **outs)
         eng.check(self.e.lib.smalfit_fit_eval(self.e.handle, eng._stream(), eng.C.byref(a)), "smalfit_fit_eval")
         return self.losses
@@ -185,14 +195,19 @@ class FusedFitter:
         eng.adam_segments(a)
         self.step_count = a.step
 
+    def _pointer_key(self, stage_id):
+        """addresses of every tensor an argument block holds a raw pointer to and that a caller may rebind (masks, targets,
+        visibility, halos): part of the plan key, so a rebound tensor gets a fresh block instead of a stale pointer"""
+        vis = self.visibility_stage0 if stage_id == 0 else self.visibility_full
+        return tuple(None if t is None else t.data_ptr() for t in
+                     (self.global_mask, self.rotation_mask, self.target_joints, vis, self.target_sil, self.halo_prev, self.halo_next))
+
     def _stage_plan(self, weights, w_temp, lr, stage_id, names):
         """argument blocks of the stage's iterations, rebuilt only when something they depend on changes.  The halo buffers
-        enter the key by ADDRESS (the block holds raw device pointers): ShardedFitter hands out views of one persistent
+        (like the masks, targets and visibility tensors: _pointer_key) enter the key by ADDRESS (the block holds raw device pointers): ShardedFitter hands out views of one persistent
         gather buffer, so the key is stable across iterations; a caller that allocates fresh halo tensors every step gets a
         fresh block every step -- correct, but it pays the ~100 us of marshalling each time (reuse the buffers instead)."""
-        key = (tuple(float(w) for w in weights), float(w_temp), float(lr), stage_id, tuple(names),
-               None if self.halo_prev is None else self.halo_prev.data_ptr(),
-               None if self.halo_next is None else self.halo_next.data_ptr())
+        key = (tuple(float(w) for w in weights), float(w_temp), float(lr), stage_id, tuple(names), self.use_joint_limits) + self._pointer_key(stage_id)
         plans = self._plan if isinstance(getattr(self, "_plan", None), dict) else {}
         if key not in plans:
             if len(plans) > 8:
@@ -215,6 +230,7 @@ class FusedFitter:
     def run_iterations(self, weights, w_temp, lr, stage_id, iterations):
         """`iterations` epochs of the reference loop in ONE library call (smalfit_fit_run): evaluation + analytic
         backward + Adam, all enqueued from C"""
+        self.assert_joint_limits()
         fa, aa = self._stage_plan(weights, w_temp, lr, stage_id, self.trainable(stage_id))
         self.e.fit_run(fa, aa, iterations)
         self.step_count = aa.step
@@ -230,11 +246,10 @@ class FusedFitter:
     def local_step(self, weights, w_temp, lr, stage_id, record):
         """evaluation + Adam on the per-frame parameters + this rank's record (partial shared gradient | boundary
         frames after the step) written into `record` (num_shared() + 216 floats)"""
+        self.assert_joint_limits()
         names = self.trainable(stage_id)
         local = tuple(k for k in names if k not in ("betas", "log_beta_scales") or (k == "log_beta_scales" and not self.ls_shared))
-        key = (tuple(float(w) for w in weights), float(w_temp), float(lr), stage_id, tuple(names), "sharded",
-               None if self.halo_prev is None else self.halo_prev.data_ptr(),
-               None if self.halo_next is None else self.halo_next.data_ptr())
+        key = (tuple(float(w) for w in weights), float(w_temp), float(lr), stage_id, tuple(names), "sharded", self.use_joint_limits) + self._pointer_key(stage_id)
         plans = self._plan if isinstance(getattr(self, "_plan", None), dict) else {}
         if key not in plans:
             if len(plans) > 8:

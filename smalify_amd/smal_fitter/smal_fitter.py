@@ -138,7 +138,7 @@ class SMALFitter(nn.Module):
             e.set_pose_prior(*self.pose_prior._data)
             e.set_shape_prior(*self._shape_prior)
             if self.enable_joint_limits:                            # reference smal_fitter.py:76-79, commented out there
-                e.set_joint_limits(*model_io.joint_limit_table())
+                e.set_joint_limits(*model_io.joint_limit_table(), owner=self)
             else:                                                   # a shared engine may carry another fitter's table
                 e.clear_joint_limits()
             e._pose_prior, e._shape_prior, e._fitter_priors = self.pose_prior._data, self._shape_prior, self

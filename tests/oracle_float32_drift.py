@@ -2,7 +2,8 @@
 four stages at iters_scale 0.1 on the 4-frame 64x64 problem of tests/parity_cases.py::case_full_schedule) run once in
 float64 and once in float32, CPU only:  python tests/oracle_float32_drift.py   (a few minutes).
 Round-2 result (8 threads): final objective 6.6e-5 relative; parameters rel-L2 betas 1.5e-3, limb scales 3.4e-4, global
-rotation 2.9e-3, joint rotations 4.9e-2, translation 1.1e-3 -- the yardstick for test_full_schedule's end-of-run numbers."""
+rotation 2.9e-3, joint rotations 4.9e-2, translation 1.1e-3 -- the yardstick for test_full_schedule's end-of-run numbers,
+written to tests/golden/oracle_full_schedule_f32_drift.json."""
 import sys, numpy as np, torch
 sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 torch.set_num_threads(8)
@@ -49,7 +50,15 @@ for name, dt in (("f64", torch.float64), ("f32", torch.float32)):
             opt.step(params, grads)
     res[name] = ({k: v.double().numpy() for k, v in params.items()}, float(total))
     print(name, "final total", float(total), flush=True)
+drift = {}
 for k in res["f64"][0]:
     a, b = res["f32"][0][k], res["f64"][0][k]
-    print("oracle f32 vs f64 param rel-L2", k, "%.2e" % (np.linalg.norm(a - b) / np.linalg.norm(b)))
-print("loss rel %.2e" % (abs(res["f32"][1] - res["f64"][1]) / abs(res["f64"][1])))
+    drift[k] = float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    print("oracle f32 vs f64 param rel-L2", k, "%.2e" % drift[k])
+drift["loss_rel"] = abs(res["f32"][1] - res["f64"][1]) / abs(res["f64"][1])
+print("loss rel %.2e" % drift["loss_rel"])
+# the yardstick tests/test_gpu_parity.py::test_full_schedule reads (ORACLE output, like oracle_full_schedule.npz)
+import json, os
+out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_full_schedule_f32_drift.json")
+json.dump({"config": dict(M=M, S=S, window=window, seed=seed, iters_scale=0.1, schedule=sched), "f32_vs_f64_rel_l2": drift}, open(out, "w"), indent=1)
+print("wrote", out)

@@ -16,7 +16,9 @@ What is asserted, and why these bounds:
   (iii) end-of-run parameters: the fit is a chaotic map over ~2000 Adam steps (a gradient component whose sign differs in
         the last float32 bit becomes a +-lr step), so float32 arithmetic alone carries ANY implementation away from the
         float64 run.  The yardstick is the oracle itself run in float32 (oracle_config2_f32.npz): per parameter tensor,
-        ||HIP - f64|| <= DRIFT_FACTOR x ||f32 oracle - f64||, at the end of every stage and of the run.
+        ||HIP - f64|| <= DRIFT_FACTOR x (the largest ||f32 oracle - f64|| at any stage end so far) AND
+        <= SAME_STAGE_FACTOR x ||f32 oracle - f64|| at the same stage end, at the end of every stage and of the run.
+The tables are printed past pytest's capture, so the driver's log of the GPU run shows them.
 """
 import numpy as np
 import pytest
@@ -28,6 +30,7 @@ HEAD = 20
 STRICT = 12
 TRACE_TOL = 1e-4
 DRIFT_FACTOR = 1.5
+SAME_STAGE_FACTOR = 2.0       # per tensor, against the float32 oracle's deviation at the SAME stage end (not only its running maximum)
 
 
 def _rel(a, b):
@@ -100,8 +103,9 @@ def test_loss_trace_follows_the_float64_oracle_at_the_head_of_every_stage(case):
             assert dev[it] < bound, (stage, it, dev[it], bound)
 
 
-def test_full_schedule_end_state_within_the_float32_yardstick(case):
+def test_full_schedule_end_state_within_the_float32_yardstick(case, capsys):
     c2, f64, f32, W = case["c2"], case["f64"], case["f32"], case["W"]
+    lines = []
     if f32 is None:
         pytest.skip("tests/golden/oracle_config2_f32.npz missing: run tests/golden/make_oracle_config2.py f32")
     f = case["new_fitter"](c2.initial_params())
@@ -129,9 +133,14 @@ def test_full_schedule_end_state_within_the_float32_yardstick(case):
         for k in c2.PARAMS:
             hip, yard = _rel(ends[stage][0][k], ref64[k]), _rel(ref32[k], ref64[k])
             yard_max[k] = max(yard_max[k], yard)
-            print("config 2, end of stage %d, %-16s rel-L2: HIP vs f64 %.2e   f32 oracle vs f64 %.2e (so far %.2e)" % (stage, k, hip, yard, yard_max[k]))
+            lines.append("config 2, end of stage %d, %-16s rel-L2: HIP vs f64 %.2e   f32 oracle vs f64 %.2e (x%.2f; so far %.2e)"
+                         % (stage, k, hip, yard, hip / max(yard, 1e-30), yard_max[k]))
             if not hip <= DRIFT_FACTOR * yard_max[k] + 1e-6:
-                failures.append((stage, k, hip, yard_max[k]))
+                failures.append(("running maximum", stage, k, hip, yard_max[k]))
+            if not hip <= SAME_STAGE_FACTOR * yard + 1e-6:
+                failures.append(("same stage", stage, k, hip, yard))
+    with capsys.disabled():
+        print("\n" + "\n".join(lines))
     assert not failures, failures
     if checked == 0:
         pytest.skip("fixtures incomplete: no stage end available yet")
@@ -145,13 +154,15 @@ def test_full_schedule_end_state_within_the_float32_yardstick(case):
         yard_abs = float(np.sum(np.abs(ref32 - ref)))
         for i, name in enumerate(c2.TERMS):
             d = abs(hip[i] - ref[i])
-            print("config 2, final %-12s HIP %.6f  f64 %.6f  |diff| %.2e   (f32 oracle |diff| %.2e, all its terms %.2e)"
-                  % (name, hip[i], ref[i], d, abs(ref32[i] - ref[i]), yard_abs))
+            with capsys.disabled():
+                print("config 2, final %-12s HIP %.6f  f64 %.6f  |diff| %.2e   (f32 oracle |diff| %.2e, all its terms %.2e)"
+                      % (name, hip[i], ref[i], d, abs(ref32[i] - ref[i]), yard_abs))
             assert d <= DRIFT_FACTOR * yard_abs, (name, d, yard_abs)
         # the total: the float32 oracle's term deviations happen to cancel (6e-5 of the total from terms off by 2e-4 .. 4e-3 each); the
         # yardstick is what they add up to without cancellation
         dt, yt = abs(hip.sum() - ref.sum()) / ref.sum(), abs(ref32.sum() - ref.sum()) / ref.sum()
         ysum = float(np.sum(np.abs(ref32 - ref))) / ref.sum()
-        print("config 2, final total: HIP %.6f  f64 %.6f  rel %.2e   (f32 oracle rel %.2e; sum of its |term deviations| %.2e)"
-              % (hip.sum(), ref.sum(), dt, yt, ysum))
+        with capsys.disabled():
+            print("config 2, final total: HIP %.6f  f64 %.6f  rel %.2e   (f32 oracle rel %.2e; sum of its |term deviations| %.2e)"
+                  % (hip.sum(), ref.sum(), dt, yt, ysum))
         assert dt <= DRIFT_FACTOR * ysum + 1e-4

@@ -15,11 +15,11 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SIZE = 64
+SIZE = 64                      # image size of the small partitions; BASELINE config 4's partition runs at its real 256 x 256
 SCHEDULE = ((0, 3), (1, 3), (2, 4))
 
 
-def _problem(n_frames, seed=21):
+def _problem(n_frames, seed=21, size=SIZE):
     """start parameters and targets of a synthetic sequence, made ONCE by the parent and handed to every rank: targets are
     rendered by the engine itself from a ground-truth pose (the comparison here is sharded vs unsharded, not HIP vs oracle;
     the oracle's CPU rasteriser would take minutes for 64 frames in each of 9 processes)"""
@@ -35,8 +35,8 @@ def _problem(n_frames, seed=21):
     cur["trans"] += (0.02 * rs.randn(n_frames, 3)).astype(np.float32)
     cur["betas"] += (0.1 * rs.randn(20)).astype(np.float32)
     _, _, dm = pc.get_model()
-    e = eng.Engine(dm, n_frames, SIZE)
-    sil = torch.empty(n_frames, SIZE, SIZE, device="cuda")
+    e = eng.Engine(dm, n_frames, size)
+    sil = torch.empty(n_frames, size, size, device="cuda")
     proj = torch.empty(n_frames, 25, 2, device="cuda")
     d = {k: pc.dev(v) for k, v in gt.items()}
     e.fit_eval(betas=d["betas"], log_beta_scales=d["log_beta_scales"], global_rotation=d["global_rotation"],
@@ -46,6 +46,7 @@ def _problem(n_frames, seed=21):
     tg = dict(tj=(proj.cpu().numpy() + rs.randn(n_frames, 25, 2)).astype(np.float32), vis=vis,
               tsil=(sil > 0.5).float().cpu().numpy())
     assert e.status() == 0 and 0.02 < tg["tsil"].mean() < 0.9
+    tg["size"] = size
     return cur, tg
 
 
@@ -68,7 +69,7 @@ def _run(fitter_factory, rank, world, n_frames, window, cur, tg):
 def _factory(pc, cur, tg, lo, hi, n_frames, window):
     from smalify_amd import engine as eng, fitter as fit, synthetic
     _, _, dm = pc.get_model()
-    e = eng.Engine(dm, hi - lo, SIZE)
+    e = eng.Engine(dm, hi - lo, int(tg.get("size", SIZE)))
     e.set_pose_prior(*synthetic.synthetic_pose_prior())
     e.set_shape_prior(*synthetic.synthetic_shape_prior())
     f = fit.FusedFitter(e, tg["tj"][lo:hi], tg["vis"][lo:hi], tg["tsil"][lo:hi], window, True, cur["betas"], cur["log_beta_scales"],
@@ -99,8 +100,45 @@ def test_two_ranks_on_one_gpu_match_the_unsharded_fit():
 
 
 def test_config4_partition_eight_ranks_of_eight_frames():
-    """BASELINE config 4's real partition on one GPU: 64 frames, WINDOW_SIZE 8, 8 ranks x 8 frames (7 interior halos)"""
-    _ranks("gloo", 8, 64, 8)
+    """BASELINE config 4's real partition AND image size on one GPU: 64 frames of 256 x 256, WINDOW_SIZE 8, 8 ranks x 8 frames
+    (7 interior halos)"""
+    _ranks("gloo", 8, 64, 8, size=256)
+
+
+def test_sharded_fit_follows_the_oracle_loop():
+    """the oracle leg: 8 frames, WINDOW_SIZE 4, 4 ranks x 2 frames at 64 x 64 -- the sharded HIP fit (halo frames, one record per
+    iteration over the collective, shared parameters stepped from the rank-ordered gradient sum) against the ORACLE's unsharded
+    loop (loss + autograd + Adam in float64 on the CPU, reference semantics optimize_to_joints.py:113-137,
+    smal_fitter.py:107-190), not just against the unsharded HIP fit: parameters within north_star's 1e-4 relative L2."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity_cases as pc
+    from oracle import smal_oracle as so
+    from smalify_amd import config as cfg
+    n_frames, window, world = 8, 4, 4
+    prob, cur, tg = pc.make_problem_cpu(n_frames, SIZE, window, seed=31)
+    tg["size"] = SIZE
+    W = np.array(cfg.OPT_WEIGHTS).T
+    params = {k: torch.from_numpy(v).double() for k, v in cur.items()}
+    for stage_id, its in SCHEDULE:
+        names = so.trainable_names(stage_id)
+        vis0 = so.stage0_visibility(prob.vis) if stage_id == 0 else None
+        opt = so.Adam(so.PARAM_ORDER, lr=float(W[stage_id][8]))
+        for _ in range(its):
+            _, _, grads = so.loss_and_grads(prob, params, W[stage_id][:6].copy(), float(W[stage_id][6]), names, visibility=vis0)
+            opt.step(params, grads)
+    got = _spawn("gloo", world, n_frames, window, cur, tg)
+    for k in ("global_rotation", "joint_rotations", "trans"):
+        both = np.concatenate([got[r][k] for r in range(world)], 0)
+        ref = params[k].numpy().reshape(both.shape)
+        err = np.linalg.norm(both - ref) / np.linalg.norm(ref)
+        assert err < 1e-4, (k, err)
+    for k in ("betas", "log_beta_scales"):
+        for r in range(1, world):
+            assert np.array_equal(got[0][k], got[r][k]), (k, r)
+        ref = params[k].numpy().reshape(got[0][k].shape)
+        err = np.linalg.norm(got[0][k] - ref) / np.linalg.norm(ref)
+        assert err < 1e-4, (k, err)
 
 
 def test_one_frame_of_a_window_per_rank():
@@ -141,9 +179,8 @@ def test_bench_launches_its_own_ranks():
     assert d["n_gpus"] == n and d["steps"] == 12 and d["value"] > 0 and d["status_bits"] == 0
 
 
-def _ranks(backend, world, n_frames, window):
-    cur, tg = _problem(n_frames)
-    single = _run(_factory, 0, 1, n_frames, window, cur, tg)
+def _spawn(backend, world, n_frames, window, cur, tg):
+    """-> {rank: final parameters} of `world` processes fitting their shards"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29700 + (os.getpid() % 1000) + 3 * world + n_frames
@@ -168,6 +205,14 @@ def _ranks(backend, world, n_frames, window):
             if p.is_alive():
                 p.kill()
     assert len(got) == world, "a rank died: exit codes %s" % [p.exitcode for p in procs]
+    return got
+
+
+def _ranks(backend, world, n_frames, window, size=SIZE):
+    cur, tg = _problem(n_frames, size=size)
+    single = _run(_factory, 0, 1, n_frames, window, cur, tg)
+    torch.cuda.empty_cache()
+    got = _spawn(backend, world, n_frames, window, cur, tg)
     for k in ("global_rotation", "joint_rotations", "trans"):
         both = np.concatenate([got[r][k] for r in range(world)], 0)
         assert both.shape == single[k].shape
