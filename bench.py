@@ -289,11 +289,9 @@ def main():
             if its == 0:
                 continue
             w = W[stage_id]
-            if use_dist:                      # the collective sits between the two halves of every iteration
-                for _ in range(its):
-                    fitter.step(w[:6], float(w[6]), float(w[8]), stage_id)
-            else:
-                fitter.run_iterations(w[:6], float(w[6]), float(w[8]), stage_id, its)
+            # one library call per stage either way: unsharded smalfit_fit_run; sharded smalfit_shard_run, which enqueues the
+            # all-gather between the two halves of every iteration itself (RCCL on the kernels' stream)
+            fitter.run_iterations(w[:6], float(w[6]), float(w[8]), stage_id, its)
         if events is not None:
             events[len(iters_per_stage)].record()
 
@@ -415,6 +413,8 @@ def main():
             "final_losses": dict(zip(eng.LOSS_NAMES, final_losses)), "status_bits": status,
             "final_state_sha256": state_sha, "kernel_source_sha": kernel_source_sha(),
         }
+        if use_dist:
+            out["collective"] = fitter._collective()[3] + ": one all-gather of %d floats per rank and iteration, enqueued by smalfit_shard_run" % (base.num_shared() + 216)
         if crop_cold is not None:
             rates = lambda r: {"stage%d" % i: (sched[i] / r["stage_seconds"][i] if r["stage_seconds"][i] > 0 and sched[i] else None)  # noqa: E731
                                for i in range(len(sched))}

@@ -34,8 +34,9 @@ typedef struct smalfit_engine smalfit_engine;
  * two once at load time (smalify_amd/_lib.py does) -- the argument structs below are passed by pointer and grow at the
  * tail from version to version.  History: 1 = round 1; 2 = 9 loss terms (losses must hold SMALFIT_NUM_LOSS_TERMS floats),
  * smalfit_fit_args gained target_sil_u8 / w_limit; 3 = smalfit_fit_args.struct_size (first field), frame_offset,
- * total_frames; smalfit_engine_clear_joint_limits, smalfit_shard_local_step. */
-#define SMALFIT_ABI_VERSION 3
+ * total_frames; smalfit_engine_clear_joint_limits, smalfit_shard_local_step; 4 = smalfit_shard_run (the sharded loop of a
+ * whole stage in one call, the collective supplied by the host as a function pointer), smalfit_rccl_allgather. */
+#define SMALFIT_ABI_VERSION 4
 int smalfit_version(void);
 const char* smalfit_last_error(void);
 
@@ -269,6 +270,40 @@ int smalfit_shard_record(void* stream, int num_shared, const float* shared_grad,
  * partial gradients, then Adam (t = adam->step + 1) on the first num_trainable of them.  gathered: (world_size, record_stride) */
 int smalfit_shard_reduce_step(void* stream, int world_size, int record_stride, const float* gathered, int num_shared,
                               int num_trainable, const smalfit_adam_args* adam);
+
+/* The sharded loop of a whole stage in ONE call (round 4; until then a host loop made one call before and one after the
+ * collective of every iteration): `iterations` x [ smalfit_shard_local_step -> all-gather of the record -> smalfit_shard_reduce_step ],
+ * everything enqueued on `stream`, nothing synchronises, no host code between two iterations.  The library links against no
+ * communication library: the collective is the caller's, handed over as a function that enqueues
+ *     all-gather of `count` floats per rank:  send (count) -> recv (world_size x count, rank-major)   on `stream`
+ * and returns 0 on success.  With RCCL that is smalfit_rccl_allgather below on the process group's own communicator (same
+ * stream as the kernels: no event hand-over per iteration); any other transport (gloo in the tests) is a host callback.
+ * `gathered` is persistent: args->halo_prev / halo_next point INTO it (row rank-1, floats [num_shared+108, num_shared+216) and
+ * row rank+1, floats [num_shared, num_shared+108)), so the all-gather of iteration i delivers the temporal halo of iteration
+ * i+1 in place; the caller fills it once before the first iteration (one stand-alone all-gather of the boundary records).
+ * adam_local: the per-frame ranges; adam_shared: the same flat buffers (its ranges are ignored: the first
+ * num_trainable_shared floats are stepped from the rank-ordered sum); both with the same `step`. */
+typedef int (*smalfit_allgather_fn)(void* ctx, const float* send, float* recv, int count, void* stream);
+typedef struct smalfit_shard_args {
+  unsigned struct_size;        /* sizeof(smalfit_shard_args) of the caller's header */
+  int world_size, rank;
+  int num_shared;              /* shared floats at the head of the flat gradient (20, or 26 with shared limb scales) */
+  int num_trainable_shared;    /* how many of them this stage trains (0 in stage 0) */
+  const float* shared_grad;    /* this rank's partial gradient of the shared parameters (num_shared), written by the evaluation */
+  float* record;               /* (num_shared + 216): the collective's send buffer */
+  float* gathered;             /* (world_size, num_shared + 216): its receive buffer */
+  smalfit_allgather_fn allgather;
+  void* allgather_ctx;
+} smalfit_shard_args;
+int smalfit_shard_run(smalfit_engine* engine, void* stream, const smalfit_fit_args* args, const smalfit_adam_args* adam_local,
+                      const smalfit_adam_args* adam_shared, const smalfit_shard_args* shard, int iterations);
+/* a smalfit_allgather_fn over RCCL without linking it: ctx points at {ncclComm_t comm; address of ncclAllGather} -- both
+ * belong to the caller's process (torch.distributed's communicator and the librccl.so it loaded) */
+typedef struct smalfit_rccl_ctx {
+  void* comm;                  /* ncclComm_t */
+  void* nccl_all_gather;       /* ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) */
+} smalfit_rccl_ctx;
+int smalfit_rccl_allgather(void* ctx, const float* send, float* recv, int count, void* stream);
 
 /* ---- Prior.__call__ ---------------------------------------------------------------------------------
  * replaces: Prior.__call__(x)                                 reference smal_fitter/priors/pose_prior_35.py:112-124

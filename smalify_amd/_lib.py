@@ -11,7 +11,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 3                    # SMALFIT_ABI_VERSION of include/smalfit.h this binding mirrors
+ABI_VERSION = 4                    # SMALFIT_ABI_VERSION of include/smalfit.h this binding mirrors
 LIB_PATH = os.environ.get("SMALFIT_LIB") or os.path.join(_HERE, "libsmalfit.so")   # override: development builds
 CSRC = os.path.join(_HERE, "csrc")
 
@@ -53,6 +53,23 @@ class LbsArgs(C.Structure):
     _fields_ = [("num_frames", C.c_int), ("num_betas", C.c_int)] + [(n, C.c_void_p) for n in (
         "beta", "theta", "Rs", "logscale", "v_offset", "verts", "joints", "Rs_out", "v_shaped", "dverts", "djoints",
         "dbeta", "dtheta", "dRs", "dlogscale", "dv_offset")]
+
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)     # smalfit_allgather_fn
+
+
+class ShardArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_uint), ("world_size", C.c_int), ("rank", C.c_int), ("num_shared", C.c_int),
+                ("num_trainable_shared", C.c_int), ("shared_grad", C.c_void_p), ("record", C.c_void_p), ("gathered", C.c_void_p),
+                ("allgather", C.c_void_p), ("allgather_ctx", C.c_void_p)]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = C.sizeof(ShardArgs)
+
+
+class RcclCtx(C.Structure):
+    _fields_ = [("comm", C.c_void_p), ("nccl_all_gather", C.c_void_p)]
 
 
 class AdamArgs(C.Structure):
@@ -114,6 +131,8 @@ SIGNATURES = {
     "smalfit_shard_local_step": (_I, [_VP, _VP, C.POINTER(FitArgs), C.POINTER(AdamArgs), _I, _VP, _VP]),
     "smalfit_shard_record": (_I, [_VP, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "smalfit_shard_reduce_step": (_I, [_VP, _I, _I, _VP, _I, _I, C.POINTER(AdamArgs)]),
+    "smalfit_shard_run": (_I, [_VP, _VP, C.POINTER(FitArgs), C.POINTER(AdamArgs), C.POINTER(AdamArgs), C.POINTER(ShardArgs), _I]),
+    "smalfit_rccl_allgather": (_I, [_VP, _VP, _VP, _I, _VP]),
     "smalfit_pose_prior": (_I, [_VP, _VP, _I, _VP, _VP]),
     "smalfit_pose_prior_backward": (_I, [_VP, _VP, _I, _VP, _VP, _VP]),
     "smalfit_temporal": (_I, [_VP, _VP, _I, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

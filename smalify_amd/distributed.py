@@ -29,8 +29,13 @@ the rank that holds the window's first frame; the sum over ranks is the sum over
 """
 from __future__ import annotations
 
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
+
+from . import _lib
 
 
 def shard_range(num_frames, rank, world_size, window=None):
@@ -83,21 +88,81 @@ class ShardedFitter:
         dist.all_gather_into_tensor(out, rec, group=self.group)
         self._set_halos(out.view(self.world, 2, 108))
 
+    # ---- the collective handed to the library (smalfit_shard_run): RCCL natively, anything else through a host callback ----
+    def _collective(self):
+        """-> (address of a smalfit_allgather_fn, context pointer or None).  With the "nccl" backend (RCCL on ROCm) the library
+        calls ncclAllGather itself, on the process group's own communicator and on the kernels' stream -- nothing of torch runs
+        per iteration; with any other backend (gloo in the tests) the function is a Python callback around
+        dist.all_gather_into_tensor on the same two buffers."""
+        if getattr(self, "_coll", None) is not None:
+            return self._coll
+        pg = self.group if self.group is not None else dist.distributed_c10d._get_default_group()
+        backend_name = dist.get_backend(pg)
+        if backend_name == "nccl" and os.environ.get("SMALFIT_SHARD_HOST_COLLECTIVE") != "1":
+            be = pg._get_backend(torch.device("cuda", torch.cuda.current_device()))
+            comm = be._comm_ptr()                       # created eagerly by init_process_group(device_id=...) or by the halo exchange
+            rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))    # the copy torch itself loaded
+            ctx = _lib.RcclCtx(comm, ctypes.cast(rccl.ncclAllGather, ctypes.c_void_p).value)
+            fn = ctypes.cast(_lib.load().smalfit_rccl_allgather, ctypes.c_void_p).value
+            self._coll = (fn, ctypes.addressof(ctx), ctx, "rccl")
+        else:
+            def gather(_ctx, _send, _recv, _count, _stream):
+                try:
+                    dist.all_gather_into_tensor(self._gather.view(-1), self._payload, group=self.group)
+                    return 0
+                except Exception as exc:                # an exception must not unwind through the C frames
+                    self._coll_error = exc
+                    return 1
+            cb = _lib.ALLGATHER_FN(gather)
+            self._coll = (ctypes.cast(cb, ctypes.c_void_p).value, None, cb, "host callback (%s)" % backend_name)
+        return self._coll
+
+    def _buffers(self):
+        f = self.fitter
+        ns = f.num_shared()
+        if self._gather is None or self._gather.numel() != self.world * (ns + 216) or self._gather.dim() != 2:
+            dev = f.flat.device
+            self._payload = torch.zeros(ns + 216, device=dev, dtype=torch.float32)
+            self._gather = torch.zeros(self.world, ns + 216, device=dev, dtype=torch.float32)
+            self._halo_valid = False
+        return ns
+
+    def run_iterations(self, weights, w_temp, lr, stage_id, iterations):
+        """`iterations` sharded iterations; with the HIP engine ONE library call (smalfit_shard_run) -- evaluation, per-frame
+        Adam, record, all-gather, rank-ordered reduction and shared Adam are all enqueued from C, the halos of the next
+        iteration arrive in place (views of the gather buffer)"""
+        f = self.fitter
+        if self.world == 1 and not self.always_exchange:
+            return f.run_iterations(weights, w_temp, lr, stage_id, iterations)
+        if not hasattr(f, "shard_run"):
+            for _ in range(iterations):
+                self.step(weights, w_temp, lr, stage_id)
+            return f.losses
+        ns = self._buffers()
+        if not self._halo_valid:
+            # the boundary records of the current state, gathered once into the persistent buffer the halos are views of
+            f.boundary_records(out=self._payload[ns:])
+            dist.all_gather_into_tensor(self._gather.view(-1), self._payload, group=self.group)
+            self._set_halos(self._gather[:, ns:].view(self.world, 2, 108))
+        fn, ctx = self._collective()[:2]
+        f.shard_run(weights, w_temp, lr, stage_id, iterations, self.rank, self.world, self._payload, self._gather, fn, ctx)
+        if getattr(self, "_coll_error", None) is not None:
+            raise self._coll_error
+        return f.losses
+
     def step(self, weights, w_temp, lr, stage_id):
         f = self.fitter
         names = f.trainable(stage_id)
         if self.world == 1 and not self.always_exchange:
             return f.step(weights, w_temp, lr, stage_id) if hasattr(f, "run_iterations") else self._plain_step(weights, w_temp, lr, stage_id)
+        if hasattr(f, "shard_run") and os.environ.get("SMALFIT_SHARD_PYTHON_LOOP") != "1":
+            return self.run_iterations(weights, w_temp, lr, stage_id, 1)
         if not self._halo_valid:
             self.exchange_halos()
         if hasattr(f, "local_step"):
             # HIP engine: evaluation + per-frame Adam + record packing are enqueued from the library (two calls), the
             # collective is the only torch op, the rank-ordered reduction + shared Adam is one more kernel
-            ns = f.num_shared()
-            if self._gather is None or self._gather.numel() != self.world * (ns + 216):
-                dev = f.flat.device
-                self._payload = torch.empty(ns + 216, device=dev, dtype=torch.float32)
-                self._gather = torch.empty(self.world, ns + 216, device=dev, dtype=torch.float32)
+            ns = self._buffers()
             f.local_step(weights, w_temp, lr, stage_id, self._payload)
             dist.all_gather_into_tensor(self._gather.view(-1), self._payload, group=self.group)
             f.shared_step(self._gather, self.world, lr, stage_id)

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import AdamArgs, FitArgs, LbsArgs, ModelDesc, SmalfitError, check
+from ._lib import AdamArgs, FitArgs, LbsArgs, ModelDesc, ShardArgs, SmalfitError, check
 
 LOSS_NAMES = ("joint", "pose", "splay", "betas", "sil_reproj", "temp_joint", "temp_global", "temp_trans", "limit")
 NUM_LOSS_TERMS = len(LOSS_NAMES)
@@ -432,6 +432,15 @@ def shard_local_step(engine, fit_args, adam_args, num_shared, shared_grad, recor
     advance adam_args.step (shard_reduce_step closes the iteration)"""
     check(engine.lib.smalfit_shard_local_step(engine.handle, _stream(), C.byref(fit_args), C.byref(adam_args), int(num_shared),
                                               _ptr(shared_grad), _ptr(record)), "smalfit_shard_local_step")
+
+
+def shard_run(engine, fit_args, adam_local, adam_shared, shard_args, iterations):
+    """`iterations` x [evaluation + per-frame Adam + record -> all-gather -> rank-ordered sum + shared Adam] in ONE library call
+    (smalfit_shard_run); advances both step counts"""
+    check(engine.lib.smalfit_shard_run(engine.handle, _stream(), C.byref(fit_args), C.byref(adam_local), C.byref(adam_shared),
+                                       C.byref(shard_args), int(iterations)), "smalfit_shard_run")
+    adam_local.step += int(iterations)
+    adam_shared.step += int(iterations)
 
 
 def shard_reduce_step(world_size, record_stride, gathered, num_shared, num_trainable, adam_args):

@@ -261,6 +261,36 @@ class FusedFitter:
         aa.step = self.step_count
         eng.shard_local_step(self.e, fa, aa, self.num_shared(), self.grad, record)
 
+    def shard_run(self, weights, w_temp, lr, stage_id, iterations, rank, world_size, record, gathered, allgather, allgather_ctx):
+        """`iterations` whole sharded iterations in ONE library call (smalfit_shard_run): evaluation + per-frame Adam + record,
+        the caller's all-gather (`allgather`: address of a smalfit_allgather_fn, `allgather_ctx`: its context) and the
+        rank-ordered reduction + shared Adam, all enqueued from C.  halo_prev / halo_next must be views of `gathered`."""
+        self.assert_joint_limits()
+        names = self.trainable(stage_id)
+        local = tuple(k for k in names if k not in ("betas", "log_beta_scales") or (k == "log_beta_scales" and not self.ls_shared))
+        ntrain = 0
+        if "betas" in names:
+            ntrain = 20 + (6 if (self.ls_shared and "log_beta_scales" in names) else 0)
+        key = (tuple(float(w) for w in weights), float(w_temp), float(lr), stage_id, tuple(names), "shard_run", self.use_joint_limits,
+               rank, world_size, record.data_ptr(), gathered.data_ptr(), int(allgather), int(allgather_ctx or 0)) + self._pointer_key(stage_id)
+        plans = self._plan if isinstance(getattr(self, "_plan", None), dict) else {}
+        if key not in plans:
+            if len(plans) > 8:
+                plans.clear()
+            fa, _, _, keep = self._fit_args(weights, w_temp, stage_id, names)
+            sa = eng.ShardArgs()
+            sa.world_size, sa.rank, sa.num_shared, sa.num_trainable_shared = int(world_size), int(rank), self.num_shared(), ntrain
+            sa.shared_grad, sa.record, sa.gathered = eng._ptr(self.grad), eng._ptr(record), eng._ptr(gathered)
+            sa.allgather, sa.allgather_ctx = int(allgather), allgather_ctx
+            plans[key] = (fa, self._adam_args(local, lr), eng.make_adam_args(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, [], lr), sa,
+                          keep + [record, gathered])
+        self._plan = plans
+        fa, al, ash, sa, _ = plans[key]
+        al.step = ash.step = self.step_count
+        eng.shard_run(self.e, fa, al, ash, sa, iterations)
+        self.step_count = al.step
+        return self.losses
+
     def shared_step(self, gathered, world_size, lr, stage_id):
         """sum of the ranks' partial shared gradients + Adam on the shared parameters the stage trains; closes the
         iteration (advances the step count)"""

@@ -60,5 +60,7 @@ print("loss rel %.2e" % drift["loss_rel"])
 # the yardstick tests/test_gpu_parity.py::test_full_schedule reads (ORACLE output, like oracle_full_schedule.npz)
 import json, os
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_full_schedule_f32_drift.json")
-json.dump({"config": dict(M=M, S=S, window=window, seed=seed, iters_scale=0.1, schedule=sched), "f32_vs_f64_rel_l2": drift}, open(out, "w"), indent=1)
-print("wrote", out)
+doc = json.load(open(out)) if os.path.exists(out) else {"config": dict(M=M, S=S, window=window, seed=seed, iters_scale=0.1, schedule=sched), "draws": []}
+doc["draws"].append(dict({"source": "tests/oracle_float32_drift.py, %d threads" % torch.get_num_threads()}, **drift))
+json.dump(doc, open(out, "w"), indent=1)
+print("appended a draw to", out)

@@ -42,7 +42,7 @@ def test_struct_layouts_match_the_header(tmp_path):
     import ctypes as C
     import subprocess
     pairs = {"smalfit_model_desc": _lib.ModelDesc, "smalfit_fit_args": _lib.FitArgs, "smalfit_fit3d_args": _lib.Fit3dArgs,
-             "smalfit_adam_args": _lib.AdamArgs}
+             "smalfit_adam_args": _lib.AdamArgs, "smalfit_shard_args": _lib.ShardArgs, "smalfit_rccl_ctx": _lib.RcclCtx}
     lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "smalfit.h"', "int main(void) {"]
     for cname, cls in pairs.items():
         lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))

@@ -132,9 +132,8 @@ def test_global_rigid_transformation_against_reference_golden(golden, scaled):
 def test_full_schedule(capsys):
     """All four stages (scaled to 15 / 40 / 60 / 80 iterations) on 4 frames at 64 x 64, HIP loop (one library call per
     stage) vs the oracle loop: the final loss terms agree (SURVEY section 7 check iii) and the end-of-run relative L2
-    difference of every parameter tensor is reported (check iv; asserted loosely -- Adam turns a gradient whose sign
-    differs in the last float32 bit into a +-lr step, so 195 iterations of float32 vs float64 part ways on the flat
-    directions of the objective while the loss does not)."""
+    difference of every parameter tensor is reported and bounded by the float32 oracle's own drift from its float64 run on
+    the same problem (check iv)."""
     m = pc.case_full_schedule(M=4, S=64, window=2, iters_scale=0.1)
     with capsys.disabled():
         print("\nfull schedule %s: final loss hip %.6f oracle %.6f (rel %.2e)" % (m["schedule"], m["final_total_hip"],
@@ -145,9 +144,20 @@ def test_full_schedule(capsys):
     assert m["final_total_rel"] < 1e-3, m
     for k in ("joint", "sil_reproj", "pose", "betas"):      # each term to 1e-3 of the objective (small terms trade against large ones)
         assert abs(m["final_%s_hip" % k] - m["final_%s_oracle" % k]) < 1e-3 * abs(m["final_total_oracle"]), (k, m)
-    for k, v in m.items():                   # reported above; bounded loosely (the float32 ORACLE drifts from the float64 one
-        if k.startswith("param_"):           # by the same order over this schedule: DESIGN.md section 6)
-            assert v < (1e-1 if "joint_rotations" in k else 2e-2), (k, v)
+    # end-of-run parameters: the yardstick is the ORACLE ITSELF in float32 against its float64 run on this very problem
+    # (tests/oracle_float32_drift.py -> tests/golden/oracle_full_schedule_f32_drift.json; Adam turns a gradient component whose
+    # sign differs in the last float32 bit into a +-lr step, so 195 float32 iterations part ways with float64 on the flat
+    # directions of the objective whoever computes them): per tensor at most FACTOR x the largest recorded draw
+    import json
+    import os
+    FACTOR = 2.0
+    doc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_full_schedule_f32_drift.json")))
+    assert doc["config"]["schedule"] == list(m["schedule"]), (doc["config"], m["schedule"])
+    for k, v in m.items():
+        if k.startswith("param_"):
+            name = k[6:-7]
+            yard = max(d[name] for d in doc["draws"])
+            assert v <= FACTOR * yard, (k, v, yard)
 
 
 def test_joint_limit_term():

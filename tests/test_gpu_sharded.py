@@ -177,6 +177,44 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == n and d["steps"] == 12 and d["value"] > 0 and d["status_bits"] == 0
+    assert d["collective"].startswith("rccl"), d["collective"]      # the library called ncclAllGather itself (smalfit_rccl_allgather)
+
+
+def test_sharded_loop_in_c_equals_the_python_loop():
+    """smalfit_shard_run (one library call per stage, the collective enqueued from C through the host-callback adapter) against
+    the round-3 host loop (one call before and one after a torch.distributed collective per iteration): the same launches in
+    the same order -- identical bits.  World of one rank with the exchange forced on, gloo."""
+    import subprocess
+    code = """
+import os, sys, hashlib
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+import numpy as np, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29900 + os.getpid() %% 90))
+dist.init_process_group('gloo', rank=0, world_size=1)
+import test_gpu_sharded as t
+from smalify_amd import config as cfg, distributed
+import parity_cases as pc
+cur, tg = t._problem(4)
+f = t._factory(pc, cur, tg, 0, 4, 4, 2)
+sf = distributed.ShardedFitter(f, 0, 1, always_exchange=True)
+W = np.array(cfg.OPT_WEIGHTS).T
+for stage_id, its in t.SCHEDULE:
+    sf.begin_stage(stage_id)
+    if os.environ.get('SMALFIT_SHARD_PYTHON_LOOP') == '1':
+        for _ in range(its):
+            sf.step(W[stage_id][:6], float(W[stage_id][6]), float(W[stage_id][8]), stage_id)
+    else:
+        sf.run_iterations(W[stage_id][:6], float(W[stage_id][6]), float(W[stage_id][8]), stage_id, its)
+print('SHA', hashlib.sha256(f.flat.cpu().numpy().tobytes() + f.losses.cpu().numpy().tobytes()).hexdigest())
+dist.destroy_process_group()
+""" % (ROOT, ROOT)
+    shas = []
+    for loop in ("0", "1"):
+        env = dict(os.environ, SMALFIT_SHARD_PYTHON_LOOP=loop)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        shas.append([l for l in out.stdout.splitlines() if l.startswith("SHA")][0])
+    assert shas[0] == shas[1], shas
 
 
 def _spawn(backend, world, n_frames, window, cur, tg):
