@@ -155,7 +155,10 @@ class SmalfitError(RuntimeError):
 def build_library(verbose=False):
     """Compile smalify_amd/csrc for gfx950 into smalify_amd/libsmalfit.so (cross-compiles without a GPU)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # -fno-slp-vectorize: the SLP vectoriser pairs scalar float32 multiply-adds into v_pk_fma_f32 / v_pk_mul_f32, which issue at 7.7
+    # cycles per wave-instruction on gfx950 against 2.6 for the scalar form (profiles/r4_ubench_valu_issue_costs.txt): two scalar
+    # instructions are faster than the packed one (the matrix-core kernels use builtins and are not affected)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared",
            os.path.join(CSRC, "smalfit_kernels.hip"), "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))

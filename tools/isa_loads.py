@@ -21,7 +21,7 @@ if "--" in args:
     args, defs = args[:i], args[i + 1:]
 src = os.path.join(root, "smalify_amd", "csrc", "smalfit_kernels.hip")
 asm = "/tmp/_isa_loads.s"
-r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", asm, src] + defs,
+r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", asm, src] + defs,
                    capture_output=True, text=True)
 if r.returncode != 0:
     raise SystemExit(r.stderr[-2000:])

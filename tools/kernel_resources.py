@@ -11,7 +11,7 @@ args = sys.argv[1:]
 if args and not args[0].startswith("-"):
     root = args.pop(0)
 src = os.path.join(root, "smalify_amd", "csrc", "smalfit_kernels.hip")
-out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared",
                       "-Rpass-analysis=kernel-resource-usage", src, "-o", "/tmp/_kres.so"] + args, capture_output=True, text=True).stderr
 cur = {}
 rows = []

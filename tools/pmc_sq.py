@@ -30,6 +30,14 @@ GROUPS = [
 ]
 
 
+def script_argv():
+    """PMC_SCRIPT = "tools/x.py args...": the script path is taken relative to the repository (the passes run from /tmp)"""
+    parts = os.environ["PMC_SCRIPT"].split()
+    if not os.path.isabs(parts[0]):
+        parts[0] = os.path.join(ROOT, parts[0])
+    return parts
+
+
 def main():
     global GROUPS
     if os.environ.get("PMC_GROUPS"):                 # e.g. PMC_GROUPS='[["TCP_TOTAL_CACHE_ACCESSES","TCP_TCC_READ_REQ"],["TA_BUSY"]]'
@@ -46,7 +54,7 @@ def main():
         names = [c for c in group if (c + " ") in listing or (c + "\n") in listing or ("Name: " + c) in listing or c in listing] or group
         d = os.path.join(out, "g%d" % gi)
         cmd = ["rocprofv3", "--pmc"] + names + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
-                                                sys.executable] + (os.environ["PMC_SCRIPT"].split() if os.environ.get("PMC_SCRIPT") else [os.path.join(ROOT, "bench.py")] + bench_args)
+                                                sys.executable] + (script_argv() if os.environ.get("PMC_SCRIPT") else [os.path.join(ROOT, "bench.py")] + bench_args)
         r = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp", env=env)
         open(os.path.join(out, "g%d.log" % gi), "w").write(" ".join(cmd) + "\n" + r.stdout[-2000:] + "\n" + r.stderr[-4000:])
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
