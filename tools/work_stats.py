@@ -34,6 +34,8 @@ def main():
         print("stage %d (%d its), per iteration:" % (stage_id, its))
         print("  sweep: pairs %.2fM  pass-depth %.3f  pass-eval %.3f  near %.3f | wave-rounds %.0fk  lane eff %.3f | flush atomics %.2fM  blocks %.0f"
               % (o[0] / 1e6, o[1] / o[0], o[2] / o[0], o[3] / o[0], o[4] / 1e3, o[0] / max(o[4] * 64, 1), o[5] / 1e6, o[6] / 4))
+        print("  sweep: near pairs outside the LDS window (one global atomic each) %.2fM = %.3f of the near pairs; workgroups whose rectangle exceeds the window %.3f"
+              % (o[7] / 1e6, o[7] / max(o[3], 1), o[31] / max(o[6], 1)))
         print("  bwd:   pairs %.2fM  live-seed %.3f  pass-eval %.3f  in-K %.3f | wave-rounds(max trips) %.0fk lane eff %.3f | rounds %.0fk dead rounds %.3f | faces with a live pixel %.3f"
               % (o[8] / 1e6, o[9] / o[8], o[10] / o[8], o[11] / o[8], o[12] / 1e3, o[8] / max(o[12] * 64, 1), o[13] / 1e3,
                  o[14] / max(o[13], 1), o[15] / max(o[16], 1)), flush=True)
