@@ -16,12 +16,17 @@ timing  : W untimed warm-up steps, then EXACTLY K steps between (barrier +) torc
           SMALFIT_BENCH_MIN_WARMUP overrides the floor for measurements of its effect);
           the JSON reports the real number.  `value` is COLD-HONEST: the rasteriser's per-pixel depth-bound cache is
           forgotten (smalfit_engine_reset_raster_cache) before the timed fit starts, so the fit pays its first exact
-          K-nearest selection inside the timed region, exactly like a fit of a new sequence does.  `value_primed` is a
+          K-nearest selection inside the timed region, exactly like a fit of a new sequence does -- and so is the host-side
+          set-up of every stage's argument block (round 3 prebuilt the four blocks before the region).  `value_primed` is a
           second, separately timed run of the same K steps after ONE untimed silhouette evaluation of the initial state --
           what a K-step window in the middle of a long fit looks like.  Neither region carries instrumentation beyond five
           stream events at the stage boundaries; the per-section HIP events behind `roofline` / `section_ms` are recorded in a
           THIRD run of the same K steps (primed; every 8th iteration), because a profiled iteration costs ~60 us of event
-          records and pipeline bubbles -- 3.4 % of a 20-step window (profiles/r3_trace_20step_gaps.txt).
+          records and pipeline bubbles.
+          `value_crop` (scene=survey runs only; --no-crop skips it) is ONE complete 1950-iteration fit, timed the same way, of the
+          crop-filling scene: the animal as large in the image as the reference's loaders deliver it (utils.py:5-36).  It does
+          not scale with --steps: every fit starts from the reference's small initial mesh, so only a complete fit spends most
+          of its iterations in that regime.
 
 multi-GPU: `python bench.py --gpus N` launches N ranks itself (torch.distributed.run, one process per GPU, RCCL)
           when it is not already running under a launcher; under `python -m torch.distributed.run ... bench.py
@@ -54,7 +59,7 @@ SCHEDULE_ITERS = (150, 400, 600, 800)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 INTERNAL_WARMUP = int(os.environ.get("SMALFIT_BENCH_MIN_WARMUP", "40"))           # minimum number of untimed iterations before the timed region
 PROFILE_STRIDE = 8
-PMC_SUMMARY = os.path.join("profiles", "r3_pmc_summary.json")
+PMC_SUMMARY = os.path.join("profiles", "r4_pmc_summary.json")
 
 
 def kernel_source_sha():

@@ -6,7 +6,7 @@ combined with tracing domains other than --kernel-trace.  Counter names that `ro
 from a group instead of failing the pass.  Writes gpurun_out/<tag>/pmc_summary.json: per kernel, per counter, the
 average per launch (summed over the dimension rows of one dispatch).
 
-usage: python tools/pmc_sq.py TAG [bench args...]        (default bench args: --steps 39 --warmup 4 --no-cpu-baseline)
+usage: python tools/pmc_sq.py TAG [bench args...]        (default bench args: --steps 39 --warmup 4 --no-cpu-baseline --no-crop)
        PMC_SCRIPT="tools/raster_probe.py" python tools/pmc_sq.py TAG      (another script of the repo instead of bench.py)
 """
 import collections
@@ -43,7 +43,7 @@ def main():
     if os.environ.get("PMC_GROUPS"):                 # e.g. PMC_GROUPS='[["TCP_TOTAL_CACHE_ACCESSES","TCP_TCC_READ_REQ"],["TA_BUSY"]]'
         GROUPS = json.loads(os.environ["PMC_GROUPS"])
     tag = sys.argv[1] if len(sys.argv) > 1 else "pmc_sq"
-    bench_args = sys.argv[2:] or ["--steps", "39", "--warmup", "4", "--no-cpu-baseline"]
+    bench_args = sys.argv[2:] or ["--steps", "39", "--warmup", "4", "--no-cpu-baseline", "--no-crop"]
     out = os.path.join(ROOT, "gpurun_out", tag)
     os.makedirs(out, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")

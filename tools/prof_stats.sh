@@ -4,7 +4,7 @@ tag=${1:-dev}; steps=${2:-390}; scene=${3:-survey}
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps $steps --scene $scene > $out/bench.json 2> $out/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-crop --steps $steps --scene $scene > $out/bench.json 2> $out/bench.err
 f=$(find $out -name '*kernel_stats.csv' | head -1)
 cp $f $out/bench_kernel_stats.csv 2>/dev/null
 python - <<PY
