@@ -39,11 +39,11 @@ def main():
         print("  bwd:   pairs %.2fM  live-seed %.3f  pass-eval %.3f  in-K %.3f | wave-rounds(max trips) %.0fk lane eff %.3f | rounds %.0fk dead rounds %.3f | faces with a live pixel %.3f"
               % (o[8] / 1e6, o[9] / o[8], o[10] / o[8], o[11] / o[8], o[12] / 1e3, o[8] / max(o[12] * 64, 1), o[13] / 1e3,
                  o[14] / max(o[13], 1), o[15] / max(o[16], 1)), flush=True)
+        print("  bwd faces: with a list %.0fk, box walk because the box exceeds 256 px %.0fk, box walk because the list overflowed / the selection flagged it %.0fk (their boxes hold %.2fM pixels)"
+              % (o[21] / 1e3, o[22] / 1e3, o[23] / 1e3, o[24] / 1e6))
         print("  bwd in-K pairs by pixel alpha: <2^-12 %.3f  <2^-24 %.3f  <2^-40 %.3f | faces whose every in-K pixel has alpha <2^-24: %.3f  <2^-12: %.3f"
               % (o[17] / max(o[11], 1), o[18] / max(o[11], 1), o[19] / max(o[11], 1), o[29] / max(o[16], 1), o[30] / max(o[16], 1)))
         nw = max(o[6], 1)
-        print("  sweep wave-cycles (avg per wave): zero-LDS %.0f  load recs %.0f  main loop %.0f  band flush %.0f  window flush %.0f"
-              % tuple(o[i] / nw for i in (20, 21, 22, 23, 24)))
         print("  bwd wave-cycles (avg per wave): rec load %.0f  pixel loop %.0f  reduce+store %.0f  (waves %.0f)"
               % (o[25] / max(o[28], 1), o[26] / max(o[28], 1), o[27] / max(o[28], 1), o[28]), flush=True)
 
