@@ -177,3 +177,98 @@ def test_byte_resident_targets_are_bit_identical():
     m = pc.case_u8_targets()
     assert m["dtype_f32"] == "torch.float32" and m["dtype_u8"] == "torch.uint8", m
     assert m["status"] == 0 and m["params_identical"] and m["losses_identical"], m
+
+
+def test_rebound_mask_and_targets_get_fresh_argument_blocks():
+    """the cached argument blocks hold raw device pointers; the plan key covers the address of every tensor a caller may rebind
+    (round-3 advisor finding): after `fitter.rotation_mask = <new tensor>` / new targets the next run must see the new tensor,
+    exactly as a fitter built with it from the start does"""
+    import numpy as np
+    from smalify_amd import fitter as fit
+    W = np.array(pc.cfg.OPT_WEIGHTS).T
+    e, prob, cur, tg = pc.make_problem(4, 64, 2, seed=33)
+
+    def run(rebind):
+        e.reset_raster_cache()                           # (which float-equivalent path sums a pixel depends on the cache: same start for all)
+        f = fit.FusedFitter(e, tg["tj"], tg["vis"], tg["tsil"], 2, True, cur["betas"], cur["log_beta_scales"])
+        for k in ("global_rotation", "joint_rotations", "trans"):
+            f.p[k].copy_(pc.dev(cur[k]))
+        mask = torch.ones(34, 3, device="cuda")
+        mask[5:9] = 0.0
+        tj2 = f.target_joints + 1.5
+        if not rebind:                                   # the new tensors from the start
+            f.rotation_mask, f.target_joints = mask, tj2
+        f.begin_stage(1)
+        f.run_iterations(W[1][:6], float(W[1][6]), float(W[1][8]), 1, 2)
+        if rebind:                                       # ... or bound after the block of this stage was built and cached
+            f.rotation_mask, f.target_joints = mask, tj2
+        f.run_iterations(W[1][:6], float(W[1][6]), float(W[1][8]), 1, 3)
+        return f.losses.cpu().numpy().copy(), f.flat.cpu().numpy().copy()
+
+    # reference behaviour: the same 5 iterations with the first two on the OLD tensors, built by hand without any cache reuse
+    l_rebound, p_rebound = run(True)
+    e.reset_raster_cache()
+    f = fit.FusedFitter(e, tg["tj"], tg["vis"], tg["tsil"], 2, True, cur["betas"], cur["log_beta_scales"])
+    for k in ("global_rotation", "joint_rotations", "trans"):
+        f.p[k].copy_(pc.dev(cur[k]))
+    f.begin_stage(1)
+    f.run_iterations(W[1][:6], float(W[1][6]), float(W[1][8]), 1, 2)
+    f._plan = None                                        # forget every cached block
+    mask = torch.ones(34, 3, device="cuda")
+    mask[5:9] = 0.0
+    f.rotation_mask, f.target_joints = mask, f.target_joints + 1.5
+    f.run_iterations(W[1][:6], float(W[1][6]), float(W[1][8]), 1, 3)
+    assert np.array_equal(p_rebound, f.flat.cpu().numpy()) and np.array_equal(l_rebound, f.losses.cpu().numpy())
+    # and the rebinding did change the fit (the test would be vacuous otherwise)
+    l_new, p_new = run(False)
+    assert not np.array_equal(p_rebound, p_new)
+    assert e.status() == 0
+
+
+def test_fused_fitter_keeps_its_joint_limits_on_a_shared_engine():
+    """the joint-limit table is engine state: a fitter that opted in re-asserts its table when another fitter replaced or cleared it
+    (round-3 advisor finding: the w_limit term used to drop out of the objective silently)"""
+    import numpy as np
+    from smalify_amd import fitter as fit, model_io
+    W = np.array(pc.cfg.OPT_WEIGHTS).T
+    e, prob, cur, tg = pc.make_problem(3, 64, 2, seed=35, with_sil=False)
+    w = W[1][:6].copy()
+    w[1] = 0.0
+    f = fit.FusedFitter(e, tg["tj"], tg["vis"], tg["tsil"], 2, True, cur["betas"], cur["log_beta_scales"])
+    f.p["joint_rotations"].copy_(pc.dev((0.6 * np.random.RandomState(3).randn(3, 34, 3)).astype(np.float32)))   # well outside the limits
+    f.enable_joint_limits()
+    f.begin_stage(1)
+    f.evaluate(w, float(W[1][6]), 1)
+    with_limits = float(f.losses[8])
+    assert with_limits > 0.0
+    e.clear_joint_limits()                                # what a limit-free SMALFitter on the same engine does
+    f.evaluate(w, float(W[1][6]), 1)
+    assert float(f.losses[8]) == with_limits
+    lo, hi = model_io.joint_limit_table()
+    e.set_joint_limits(lo - 10.0, hi + 10.0, owner="somebody else")    # ... or another fitter's (much wider) table
+    f.run_iterations(w, float(W[1][6]), 0.0, 1, 1)                     # lr 0: the state does not move
+    assert float(f.losses[8]) == with_limits
+    assert e.status() == 0
+
+
+def test_silhouette_loss_with_and_without_the_image_output():
+    """raster_resolve_kernel sums the targets of a workgroup wholly outside the frame's active region in one wave when no silhouette
+    image is asked for, and per thread otherwise (round-3 advisor finding): the reported sil_reproj loss may differ in its last
+    bits between the two, never by more than float32 summation noise; gradients are identical"""
+    import numpy as np
+    W = np.array(pc.cfg.OPT_WEIGHTS).T
+    e, prob, cur, tg = pc.make_problem(4, 64, 2, seed=37)
+    d = {k: pc.dev(v) for k, v in cur.items()}
+    out = {}
+    for tag, sil_out in (("plain", None), ("image", torch.empty(4, 64, 64, device="cuda"))):
+        e.reset_raster_cache()
+        losses, grads = e.fit_eval(betas=d["betas"], log_beta_scales=d["log_beta_scales"], global_rotation=d["global_rotation"],
+                                   joint_rotations=d["joint_rotations"], trans=d["trans"], target_joints=pc.dev(tg["tj"]),
+                                   target_visibility=pc.dev(tg["vis"]), target_sil=pc.dev(tg["tsil"]), weights=W[2][:6].copy(),
+                                   w_temp=float(W[2][6]), window=2, sil_out=sil_out)
+        out[tag] = (losses.cpu().numpy().copy(), {k: v.cpu().numpy().copy() for k, v in grads.items()})
+    a, b = out["plain"][0][4], out["image"][0][4]
+    assert abs(a - b) <= 2e-6 * abs(b), (a, b)
+    for k in out["plain"][1]:
+        assert np.array_equal(out["plain"][1][k], out["image"][1][k]), k
+    assert e.status() == 0
