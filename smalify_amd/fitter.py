@@ -110,6 +110,10 @@ class FusedFitter:
         self.halo_prev = self.halo_next = None
         self._plan = None
         self.use_joint_limits = False          # opt-in (enable_joint_limits): the reference's term is commented out
+        # the two argument-block templates (stage 0 / later stages differ in the visibility tensor) are marshalled here, with the
+        # rest of the construction, not in front of the first launch of the first stage
+        for stage_id in (0, 1):
+            self._fit_args((0, 0, 0, 0, 0, 0), 0.0, stage_id, PARAM_NAMES)
 
     def enable_joint_limits(self, min_values=None, max_values=None):
         """switch on the joint-limit hinge the reference has commented out (smal_fitter.py:76-79,146-151): from then on
@@ -163,17 +167,43 @@ class FusedFitter:
     # ---- one epoch (optimize_to_joints.py:113-137) ---------------------------------------------------------
     def _fit_args(self, weights, w_temp, stage_id, want, **outs):
         vis = self.visibility_stage0 if stage_id == 0 else self.visibility_full
+        weights = [float(w) for w in weights]
         if not self.use_joint_limits:          # the engine's limit table may belong to another fitter: w_limit is per call
-            weights = [float(w) for w in weights]
             weights[4] = 0.0
-        return self.e.build_fit_args(
-            betas=self.p["betas"], log_beta_scales=self.p["log_beta_scales"],
-            global_rotation=self.p["global_rotation"], joint_rotations=self.p["joint_rotations"],
-            trans=self.p["trans"], target_joints=self.target_joints, target_visibility=vis,
-            target_sil=self.target_sil, weights=weights, w_temp=w_temp, window=self.window,
-            temporal=True, global_mask=self.global_mask, rotation_mask=self.rotation_mask,
-            halo_prev=self.halo_prev, halo_next=self.halo_next,
-            losses=self.losses, grads=self.g, want=want, frame_offset=self.frame_offset, total_frames=self.total_frames, **outs)
+        if outs:                               # extra outputs (silhouette image, projections, vertices): the general path
+            return self.e.build_fit_args(
+                betas=self.p["betas"], log_beta_scales=self.p["log_beta_scales"],
+                global_rotation=self.p["global_rotation"], joint_rotations=self.p["joint_rotations"],
+                trans=self.p["trans"], target_joints=self.target_joints, target_visibility=vis,
+                target_sil=self.target_sil, weights=weights, w_temp=w_temp, window=self.window,
+                temporal=True, global_mask=self.global_mask, rotation_mask=self.rotation_mask,
+                halo_prev=self.halo_prev, halo_next=self.halo_next,
+                losses=self.losses, grads=self.g, want=want, frame_offset=self.frame_offset, total_frames=self.total_frames)
+        # Every pointer of the block is known once the fitter exists: it is marshalled ONCE per set of tensors (~100 us of ctypes work:
+        # 35 checked pointers) and a stage's block is a copy of that template with the handful of per-stage fields set -- a stage
+        # change costs the host ~10 us instead of ~100 (it sits in front of the first launch of every stage).
+        pk = self._pointer_key(stage_id)
+        bases = self.__dict__.setdefault("_arg_templates", {})
+        base = bases.get(pk)
+        if base is None:
+            if len(bases) > 8:
+                bases.clear()
+            a, _, _, keep = self.e.build_fit_args(
+                betas=self.p["betas"], log_beta_scales=self.p["log_beta_scales"],
+                global_rotation=self.p["global_rotation"], joint_rotations=self.p["joint_rotations"],
+                trans=self.p["trans"], target_joints=self.target_joints, target_visibility=vis,
+                target_sil=self.target_sil, weights=(0, 0, 0, 0, 0, 0), w_temp=0.0, window=self.window,
+                temporal=True, global_mask=self.global_mask, rotation_mask=self.rotation_mask,
+                halo_prev=self.halo_prev, halo_next=self.halo_next,
+                losses=self.losses, grads=self.g, want=PARAM_NAMES, frame_offset=self.frame_offset, total_frames=self.total_frames)
+            base = bases[pk] = (bytes(a), keep)
+        a = eng.FitArgs.from_buffer_copy(base[0])
+        a.w_j2d, a.w_sil, a.w_betas, a.w_pose, a.w_limit, a.w_splay = weights
+        a.w_temp = float(w_temp)
+        for k in PARAM_NAMES:
+            if k not in want:
+                setattr(a, "g_" + k, None)
+        return a, self.losses, self.g, base[1]
 
     def evaluate(self, weights, w_temp, stage_id, want=None, **outs):
         want = self.trainable(stage_id) if want is None else want
