@@ -98,13 +98,22 @@ class ShardedFitter:
             return self._coll
         pg = self.group if self.group is not None else dist.distributed_c10d._get_default_group()
         backend_name = dist.get_backend(pg)
+        native = None
         if backend_name == "nccl" and os.environ.get("SMALFIT_SHARD_HOST_COLLECTIVE") != "1":
-            be = pg._get_backend(torch.device("cuda", torch.cuda.current_device()))
-            comm = be._comm_ptr()                       # created eagerly by init_process_group(device_id=...) or by the halo exchange
-            rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))    # the copy torch itself loaded
-            ctx = _lib.RcclCtx(comm, ctypes.cast(rccl.ncclAllGather, ctypes.c_void_p).value)
-            fn = ctypes.cast(_lib.load().smalfit_rccl_allgather, ctypes.c_void_p).value
-            self._coll = (fn, ctypes.addressof(ctx), ctx, "rccl")
+            try:
+                be = pg._get_backend(torch.device("cuda", torch.cuda.current_device()))
+                comm = be._comm_ptr()                   # created eagerly by init_process_group(device_id=...) or by the halo exchange
+                rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))    # the copy torch itself loaded
+                if not comm:
+                    raise RuntimeError("the process group has no communicator yet")
+                ctx = _lib.RcclCtx(comm, ctypes.cast(rccl.ncclAllGather, ctypes.c_void_p).value)
+                native = (ctypes.cast(_lib.load().smalfit_rccl_allgather, ctypes.c_void_p).value, ctypes.addressof(ctx), ctx, "rccl")
+            except (AttributeError, OSError, RuntimeError) as exc:   # another torch build: no _comm_ptr / librccl elsewhere
+                import warnings
+                warnings.warn("smalify_amd: cannot hand torch's RCCL communicator to the library (%s); the all-gather of the sharded loop "
+                              "goes through torch.distributed (a host callback per iteration) instead" % exc)
+        if native is not None:
+            self._coll = native
         else:
             def gather(_ctx, _send, _recv, _count, _stream):
                 try:
