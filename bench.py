@@ -325,16 +325,12 @@ def main():
             # stream time and stalls the launch pipeline: kept out of the two regions the rates are quoted on)
             base.e.profile_begin(sum(sched_), PROFILE_STRIDE)
         stage_events = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-        import gc
-        gc.collect()
-        gc.disable()                                   # (no collector pause inside a region that may be 8 ms long)
         sync()
         t0 = time.perf_counter()
         run(fitter, sched_, stage_events)
         t_issued = time.perf_counter() - t0
         sync()
         elapsed = time.perf_counter() - t0
-        gc.enable()
         if use_dist:
             tmax = torch.tensor([elapsed], device="cuda")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
