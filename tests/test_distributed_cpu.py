@@ -117,8 +117,11 @@ def _worker(rank, world, port, out_q, N=4, window=2):
     w1[1] = 0.0
     for stage_id, its in ((0, 2), (1, 3)):
         f.begin_stage(stage_id)
-        for _ in range(its):
-            f.step(W[0][:6] if stage_id == 0 else w1, float(W[stage_id][6]), float(W[stage_id][8]), stage_id)
+        if stage_id == 0:        # both entry points of the sharded loop: per iteration ...
+            for _ in range(its):
+                f.step(W[0][:6], float(W[stage_id][6]), float(W[stage_id][8]), stage_id)
+        else:                    # ... and a whole stage at once (one library call with the HIP engine; a loop over step() for a
+            f.run_iterations(w1, float(W[stage_id][6]), float(W[stage_id][8]), stage_id, its)    # local fitter without shard_run)
     out_q.put((rank, (lo, hi), {k: v.numpy() for k, v in f.fitter.p.items()}))
     dist.barrier()
     dist.destroy_process_group()
