@@ -55,6 +55,18 @@ def shard_range(num_frames, rank, world_size, window=None):
 SHARED_NAMES = ("betas", "log_beta_scales")
 
 
+def _loaded_library(stem):
+    """path of the shared object whose file name starts with `stem` among those ALREADY mapped into this process
+    (/proc/self/maps): dlopen of that exact path returns the loaded instance, so the communicator torch created is only ever
+    handed to the library instance that created it.  Raises OSError when none is mapped."""
+    with open("/proc/self/maps") as maps:
+        for line in maps:
+            path = line.rsplit(None, 1)[-1]
+            if os.path.basename(path).startswith(stem) and ".so" in path:
+                return path
+    raise OSError("%s is not loaded in this process" % stem)
+
+
 class ShardedFitter:
     """Wraps a local fitter (FusedFitter protocol: evaluate / apply_adam / shared_grad / boundary_records /
     halo_prev / halo_next / trainable / begin_stage / losses) for rank `rank` of `world_size`."""
@@ -103,7 +115,7 @@ class ShardedFitter:
             try:
                 be = pg._get_backend(torch.device("cuda", torch.cuda.current_device()))
                 comm = be._comm_ptr()                   # created eagerly by init_process_group(device_id=...) or by the halo exchange
-                rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))    # the copy torch itself loaded
+                rccl = ctypes.CDLL(_loaded_library("librccl"))    # the copy this process already mapped (torch's), never a second one
                 if not comm:
                     raise RuntimeError("the process group has no communicator yet")
                 ctx = _lib.RcclCtx(comm, ctypes.cast(rccl.ncclAllGather, ctypes.c_void_p).value)
@@ -136,27 +148,47 @@ class ShardedFitter:
             self._halo_valid = False
         return ns
 
+    def _halos_alias_gather(self):
+        """True when both halo pointers the local fitter holds are views INTO the persistent gather buffer"""
+        g = self._gather
+        if g is None:
+            return False
+        lo, hi = g.data_ptr(), g.data_ptr() + g.numel() * g.element_size()
+        f = self.fitter
+        want = [(self.rank > 0, f.halo_prev), (self.rank + 1 < self.world, f.halo_next)]
+        return all((h is not None and lo <= h.data_ptr() < hi) if needed else h is None for needed, h in want)
+
     def run_iterations(self, weights, w_temp, lr, stage_id, iterations):
         """`iterations` sharded iterations; with the HIP engine ONE library call (smalfit_shard_run) -- evaluation, per-frame
         Adam, record, all-gather, rank-ordered reduction and shared Adam are all enqueued from C, the halos of the next
         iteration arrive in place (views of the gather buffer)"""
         f = self.fitter
-        if self.world == 1 and not self.always_exchange:
+        if self.world == 1 and not self.always_exchange and hasattr(f, "run_iterations"):
             return f.run_iterations(weights, w_temp, lr, stage_id, iterations)
         if not hasattr(f, "shard_run"):
             for _ in range(iterations):
                 self.step(weights, w_temp, lr, stage_id)
             return f.losses
         ns = self._buffers()
-        if not self._halo_valid:
+        if not (self._halo_valid and self._halos_alias_gather()):
+            # (smalfit_shard_run reads the halos of iteration i+1 out of the gather buffer: halos that exchange_halos() or the
+            # host loop left pointing at some other tensor would stay frozen at their values for the whole call)
             # the boundary records of the current state, gathered once into the persistent buffer the halos are views of
             f.boundary_records(out=self._payload[ns:])
             dist.all_gather_into_tensor(self._gather.view(-1), self._payload, group=self.group)
             self._set_halos(self._gather[:, ns:].view(self.world, 2, 108))
         fn, ctx = self._collective()[:2]
-        f.shard_run(weights, w_temp, lr, stage_id, iterations, self.rank, self.world, self._payload, self._gather, fn, ctx)
-        if getattr(self, "_coll_error", None) is not None:
-            raise self._coll_error
+        self._coll_error = None
+        try:
+            f.shard_run(weights, w_temp, lr, stage_id, iterations, self.rank, self.world, self._payload, self._gather, fn, ctx)
+        except Exception as exc:
+            # the library reports a failed collective as an error code; the exception the host callback caught is the cause.
+            # Parameters and halos are in an unknown state after a failed collective: the next call re-gathers.
+            self._halo_valid = False
+            cause, self._coll_error = self._coll_error, None
+            if cause is not None:
+                raise exc from cause
+            raise
         return f.losses
 
     def step(self, weights, w_temp, lr, stage_id):

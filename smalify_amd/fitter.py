@@ -178,7 +178,7 @@ class FusedFitter:
                 target_sil=self.target_sil, weights=weights, w_temp=w_temp, window=self.window,
                 temporal=True, global_mask=self.global_mask, rotation_mask=self.rotation_mask,
                 halo_prev=self.halo_prev, halo_next=self.halo_next,
-                losses=self.losses, grads=self.g, want=want, frame_offset=self.frame_offset, total_frames=self.total_frames)
+                losses=self.losses, grads=self.g, want=want, frame_offset=self.frame_offset, total_frames=self.total_frames, **outs)
         # Every pointer of the block is known once the fitter exists: it is marshalled ONCE per set of tensors (~100 us of ctypes work:
         # 35 checked pointers) and a stage's block is a copy of that template with the handful of per-stage fields set -- a stage
         # change costs the host ~10 us instead of ~100 (it sits in front of the first launch of every stage).

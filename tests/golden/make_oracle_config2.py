@@ -24,7 +24,11 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
-from tests import config2_case as c2       # noqa: E402
+from tests import config2_case as _cases    # noqa: E402
+
+# the case the generator runs: SMALFIT_ORACLE_CASE = config2 (default) | config1 (ONE image, all stages, crop-filling scene;
+# writes tests/golden/oracle_config1_{f64,f32,heads}.npz)
+c2 = _cases.CASES[os.environ.get("SMALFIT_ORACLE_CASE", "config2")]
 
 
 def write(tag, dtype, fp, tg, trace, stage_start, final, complete):
@@ -86,7 +90,7 @@ def main():
     start = c2.initial_params()
     fp = c2.fingerprint(tg, start)
     prob = c2.problem(md, tg, dtype)
-    ckpt = "/tmp/oracle_config2_%s.ckpt" % tag
+    ckpt = "/tmp/oracle_%s_%s.ckpt" % (c2.name, tag)
     state = None
     if os.path.exists(ckpt):
         saved = pickle.load(open(ckpt, "rb"))

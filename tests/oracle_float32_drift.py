@@ -6,7 +6,7 @@ rotation 2.9e-3, joint rotations 4.9e-2, translation 1.1e-3 -- the yardstick for
 written to tests/golden/oracle_full_schedule_f32_drift.json."""
 import sys, numpy as np, torch
 sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
-torch.set_num_threads(8)
+torch.set_num_threads(int(sys.argv[1]) if len(sys.argv) > 1 else 8)
 from oracle import smal_oracle as so
 from smalify_amd import config as cfg, synthetic, model_io
 def random_pose(M, seed, scale=1.0, z=1.45):
@@ -48,7 +48,7 @@ for name, dt in (("f64", torch.float64), ("f32", torch.float32)):
         for _ in range(sched[stage]):
             total, sums, grads = so.loss_and_grads(prob, params, w[:6].copy(), float(w[6]), names, visibility=v0)
             opt.step(params, grads)
-    res[name] = ({k: v.double().numpy() for k, v in params.items()}, float(total))
+    res[name] = ({k: v.double().numpy() for k, v in params.items()}, float(total), dict(sums))
     print(name, "final total", float(total), flush=True)
 drift = {}
 for k in res["f64"][0]:
@@ -57,6 +57,11 @@ for k in res["f64"][0]:
     print("oracle f32 vs f64 param rel-L2", k, "%.2e" % drift[k])
 drift["loss_rel"] = abs(res["f32"][1] - res["f64"][1]) / abs(res["f64"][1])
 print("loss rel %.2e" % drift["loss_rel"])
+# per-term final losses of both runs (round 5): the yardstick of test_full_schedule's per-term check -- every term of the HIP fit within
+# FACTOR x the SUM of the float32 oracle's |term deviations| (one term's own deviation is a single heavy-tailed draw)
+drift["terms_f64"] = {k: float(v) for k, v in res["f64"][2].items()}
+drift["terms_abs_dev"] = {k: abs(float(res["f32"][2][k]) - float(v)) for k, v in res["f64"][2].items()}
+print("per-term |f32 - f64|:", drift["terms_abs_dev"])
 # the yardstick tests/test_gpu_parity.py::test_full_schedule reads (ORACLE output, like oracle_full_schedule.npz)
 import json, os
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_full_schedule_f32_drift.json")
