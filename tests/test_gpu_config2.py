@@ -38,12 +38,15 @@ def _rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-@pytest.fixture(scope="module")
-def case():
-    from tests import config2_case as c2
+@pytest.fixture(scope="module", params=["config2", "config1"])
+def case(request):
+    """config2 = BASELINE config 2's shape (8 frames, WINDOW 8, the headline scene's draw); config1 (round 5) = BASELINE config 1 as
+    worded -- ONE image, shape family 1, ALL stages -- at 256 x 256 on the crop-filling scene (tests/config2_case.py)"""
+    from tests import config2_case as cases
+    c2 = cases.CASES[request.param]
     f64 = c2.load_fixture("f64")
     if f64 is None or "targets" not in f64:
-        pytest.skip("tests/golden/oracle_config2_f64.npz missing: run tests/golden/make_oracle_config2.py f64")
+        pytest.skip("tests/golden/oracle_%s_f64.npz missing: run SMALFIT_ORACLE_CASE=%s tests/golden/make_oracle_config2.py f64" % (c2.name, c2.name))
     from smalify_amd import config as cfg, engine as eng, fitter as fit, synthetic
     md = synthetic.synthetic_model(seed=0, shape_family_id=1)
     e = eng.Engine(eng.DeviceModel(md), c2.FRAMES, c2.IMAGE_SIZE)
@@ -75,7 +78,7 @@ def test_loss_trace_follows_the_float64_oracle_at_the_head_of_every_stage(case):
     starts = np.concatenate([[0], np.cumsum(c2.SCHEDULE)])
     heads = case["heads"]
     if heads is None or str(heads["fingerprint"]) != f64["fingerprint"]:
-        pytest.skip("tests/golden/oracle_config2_heads.npz missing or stale: run tests/golden/make_oracle_config2.py heads")
+        pytest.skip("tests/golden/oracle_%s_heads.npz missing or stale: run tests/golden/make_oracle_config2.py heads" % c2.name)
     worst = {}
     for stage in range(4):
         if stage not in f64["stage_start"] or len(f64["trace"]) < starts[stage] + HEAD:
@@ -94,8 +97,8 @@ def test_loss_trace_follows_the_float64_oracle_at_the_head_of_every_stage(case):
         ref64 = f64["trace"][starts[stage]:starts[stage] + HEAD].sum(1)
         yard = np.abs(heads["stage%d_f32_trace" % stage][:HEAD + 1].sum(1)[:HEAD] - ref64) / np.abs(ref64)
         worst[stage] = (dev, yard)
-        print("config 2, stage %d, loss trace vs float64 oracle, %d iterations:\n   HIP        %s\n   f32 oracle %s"
-              % (stage, HEAD, " ".join("%.0e" % d for d in dev), " ".join("%.0e" % d for d in yard)))
+        print("%s, stage %d, loss trace vs float64 oracle, %d iterations:\n   HIP        %s\n   f32 oracle %s"
+              % (c2.name, stage, HEAD, " ".join("%.0e" % d for d in dev), " ".join("%.0e" % d for d in yard)))
     assert case["e"].status() == 0 and worst
     for stage, (dev, yard) in worst.items():
         for it in range(HEAD):
@@ -107,7 +110,7 @@ def test_full_schedule_end_state_within_the_float32_yardstick(case, capsys):
     c2, f64, f32, W = case["c2"], case["f64"], case["f32"], case["W"]
     lines = []
     if f32 is None:
-        pytest.skip("tests/golden/oracle_config2_f32.npz missing: run tests/golden/make_oracle_config2.py f32")
+        pytest.skip("tests/golden/oracle_%s_f32.npz missing: run tests/golden/make_oracle_config2.py f32" % c2.name)
     f = case["new_fitter"](c2.initial_params())
     ends = {}
     for stage in range(4):
@@ -133,8 +136,8 @@ def test_full_schedule_end_state_within_the_float32_yardstick(case, capsys):
         for k in c2.PARAMS:
             hip, yard = _rel(ends[stage][0][k], ref64[k]), _rel(ref32[k], ref64[k])
             yard_max[k] = max(yard_max[k], yard)
-            lines.append("config 2, end of stage %d, %-16s rel-L2: HIP vs f64 %.2e   f32 oracle vs f64 %.2e (x%.2f; so far %.2e)"
-                         % (stage, k, hip, yard, hip / max(yard, 1e-30), yard_max[k]))
+            lines.append("%s, end of stage %d, %-16s rel-L2: HIP vs f64 %.2e   f32 oracle vs f64 %.2e (x%.2f; so far %.2e)"
+                         % (c2.name, stage, k, hip, yard, hip / max(yard, 1e-30), yard_max[k]))
             if not hip <= DRIFT_FACTOR * yard_max[k] + 1e-6:
                 failures.append(("running maximum", stage, k, hip, yard_max[k]))
             if not hip <= SAME_STAGE_FACTOR * yard + 1e-6:
@@ -155,14 +158,14 @@ def test_full_schedule_end_state_within_the_float32_yardstick(case, capsys):
         for i, name in enumerate(c2.TERMS):
             d = abs(hip[i] - ref[i])
             with capsys.disabled():
-                print("config 2, final %-12s HIP %.6f  f64 %.6f  |diff| %.2e   (f32 oracle |diff| %.2e, all its terms %.2e)"
-                      % (name, hip[i], ref[i], d, abs(ref32[i] - ref[i]), yard_abs))
+                print("%s, final %-12s HIP %.6f  f64 %.6f  |diff| %.2e   (f32 oracle |diff| %.2e, all its terms %.2e)"
+                      % (c2.name, name, hip[i], ref[i], d, abs(ref32[i] - ref[i]), yard_abs))
             assert d <= DRIFT_FACTOR * yard_abs, (name, d, yard_abs)
         # the total: the float32 oracle's term deviations happen to cancel (6e-5 of the total from terms off by 2e-4 .. 4e-3 each); the
         # yardstick is what they add up to without cancellation
         dt, yt = abs(hip.sum() - ref.sum()) / ref.sum(), abs(ref32.sum() - ref.sum()) / ref.sum()
         ysum = float(np.sum(np.abs(ref32 - ref))) / ref.sum()
         with capsys.disabled():
-            print("config 2, final total: HIP %.6f  f64 %.6f  rel %.2e   (f32 oracle rel %.2e; sum of its |term deviations| %.2e)"
-                  % (hip.sum(), ref.sum(), dt, yt, ysum))
+            print("%s, final total: HIP %.6f  f64 %.6f  rel %.2e   (f32 oracle rel %.2e; sum of its |term deviations| %.2e)"
+                  % (c2.name, hip.sum(), ref.sum(), dt, yt, ysum))
         assert dt <= DRIFT_FACTOR * ysum + 1e-4

@@ -142,8 +142,6 @@ def test_full_schedule(capsys):
         print("  end-of-run parameter rel-L2: " + ", ".join("%s %.2e" % (k[6:-7], v) for k, v in m.items() if k.startswith("param_")))
     assert m["status"] == 0
     assert m["final_total_rel"] < 1e-3, m
-    for k in ("joint", "sil_reproj", "pose", "betas"):      # each term to 1e-3 of the objective (small terms trade against large ones)
-        assert abs(m["final_%s_hip" % k] - m["final_%s_oracle" % k]) < 1e-3 * abs(m["final_total_oracle"]), (k, m)
     # end-of-run parameters: the yardstick is the ORACLE ITSELF in float32 against its float64 run on this very problem
     # (tests/oracle_float32_drift.py -> tests/golden/oracle_full_schedule_f32_drift.json; Adam turns a gradient component whose
     # sign differs in the last float32 bit into a +-lr step, so 195 float32 iterations part ways with float64 on the flat
@@ -153,6 +151,18 @@ def test_full_schedule(capsys):
     FACTOR = 2.0
     doc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_full_schedule_f32_drift.json")))
     assert doc["config"]["schedule"] == list(m["schedule"]), (doc["config"], m["schedule"])
+    # final loss terms (round 5; until then: each within 1e-3 of the whole objective, which let the joint term pass 2.2 % off): the
+    # yardstick is what the float32 ORACLE's terms deviate by from its float64 run on this problem ALTOGETHER (absolute; one term's own
+    # deviation is a single heavy-tailed draw of a chaotic trajectory, as in tests/test_gpu_config2.py) -- per term at most FACTOR x that
+    with_terms = [d for d in doc["draws"] if "terms_abs_dev" in d]
+    assert with_terms, "run tests/oracle_float32_drift.py: the yardstick file has no per-term draw yet"
+    yard_abs = max(sum(d["terms_abs_dev"].values()) for d in with_terms)
+    with capsys.disabled():
+        print("  per term |HIP - f64 oracle| (float32 oracle: all its terms together %.3f): " % yard_abs +
+              ", ".join("%s %.3f" % (k, abs(m["final_%s_hip" % k] - m["final_%s_oracle" % k]))
+                        for k in ("joint", "pose", "splay", "betas", "sil_reproj", "temp_joint", "temp_global", "temp_trans")))
+    for k in ("joint", "pose", "splay", "betas", "sil_reproj", "temp_joint", "temp_global", "temp_trans"):
+        assert abs(m["final_%s_hip" % k] - m["final_%s_oracle" % k]) <= FACTOR * yard_abs, (k, m, yard_abs)
     for k, v in m.items():
         if k.startswith("param_"):
             name = k[6:-7]

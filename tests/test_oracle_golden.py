@@ -276,16 +276,19 @@ def test_full_schedule_fixture_is_current():
     np.testing.assert_allclose(sum(float(z[k]) for k in z.files if k.startswith("sum_")), z["trace"][-1], rtol=1e-9)
 
 
-def test_config2_fixtures_are_current():
-    """tests/golden/oracle_config2_{f64,f32,heads}.npz (BASELINE config 2's shape: 8 frames, 256 x 256, WINDOW_SIZE 8, the full
+@pytest.mark.parametrize("case_name", ["config2", "config1"])
+def test_config2_fixtures_are_current(case_name):
+    """(config1, round 5: BASELINE config 1 as worded -- one image, all stages -- tests/golden/oracle_config1_*.npz, same generator)
+    tests/golden/oracle_config2_{f64,f32,heads}.npz (BASELINE config 2's shape: 8 frames, 256 x 256, WINDOW_SIZE 8, the full
     150/400/600/800 schedule; hours of oracle CPU time, tests/golden/make_oracle_config2.py) belong to the problem
     tests/config2_case.py builds today and to today's oracle: same inputs bit for bit, and the head of the float64 loop --
     three keypoint iterations of stage 0, then the first silhouette iteration from the stored stage-1 start -- reproduces the
     stored trace."""
     import torch
-    from tests import config2_case as c2
+    from tests import config2_case as cases
     from oracle import smal_oracle as so
     from smalify_amd import config as cfg
+    c2 = cases.CASES[case_name]
     f64 = c2.load_fixture("f64")
     assert f64 is not None and f64["complete"], "run tests/golden/make_oracle_config2.py f64"
     md, tg = c2.targets()
@@ -309,3 +312,42 @@ def test_config2_fixtures_are_current():
     np.testing.assert_allclose([sums.get(k, 0.0) for k in c2.TERMS], ref, rtol=1e-9, atol=1e-12)
     # the float32 run is a float32 run: it leaves the float64 trace, but not by much in the first iterations
     assert 0.0 < abs(f32["trace"][0].sum() - f64["trace"][0].sum()) / f64["trace"][0].sum() < 1e-5
+
+
+@pytest.mark.parametrize("case", ["crop8", "config3"])
+def test_eval_fixtures_are_current(case):
+    """tests/golden/oracle_eval_<case>.npz (float64 losses + gradients of one epoch objective at BASELINE's own sizes: the
+    crop-filling scene at 8 x 256^2 and the headline workload at 64 x 256^2; tests/eval_cases.py, tests/golden/make_oracle_eval.py)
+    belong to today's problem and today's oracle: the targets are reproduced bit for bit (crop8: the oracle renders them again here;
+    config3: their fingerprint), every state the fixture holds is the state tests/eval_cases.py builds (the HIP-made states: the
+    committed dump), and the float64 terms of one state are recomputed (crop8: `near_gt`, ~15 s; config3: the keypoint / prior /
+    temporal terms of `initial`, which need no rasteriser)."""
+    import torch
+    from tests import eval_cases as ec
+    from oracle import smal_oracle as so
+    fx, tg = ec.load_fixture(case), ec.load_targets(case)
+    assert fx is not None and tg is not None, "run tests/golden/make_oracle_eval.py"
+    st = ec.states(case)
+    assert set(fx["states"]) == set(ec.CASES[case]["states"]), "states missing: rerun tests/golden/make_oracle_eval.py eval %s" % case
+    assert fx["fingerprint"] == ec.fingerprint(tg, st)
+    for name, s_ in fx["states"].items():
+        assert s_["stage"] == ec.STATE_STAGE[name]
+        for k in ec.PARAMS:
+            np.testing.assert_array_equal(s_["params"][k], st[name][k])
+        assert "terms_f32" in s_ and set(s_["grads"]) == set(so.trainable_names(s_["stage"]))
+    if case == "crop8":
+        again = ec.make_targets(case)
+        for k in tg:
+            np.testing.assert_array_equal(again[k], tg[k])
+        torch.set_num_threads(4)
+        terms, grads = ec.oracle_eval(ec.problem(case, tg), st["near_gt"], ec.STATE_STAGE["near_gt"])
+        np.testing.assert_allclose(terms, fx["states"]["near_gt"]["terms"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(grads["trans"], fx["states"]["near_gt"]["grads"]["trans"], rtol=1e-7, atol=1e-10)
+    else:
+        prob = ec.problem(case, tg)
+        weights, w_temp, _ = ec.stage_weights(1)
+        p = {k: torch.from_numpy(np.asarray(v)).double() for k, v in st["initial"].items()}
+        _, sums = so.epoch_loss(prob, p, weights, w_temp, with_sil=False)
+        ref = dict(zip(ec.TERMS, fx["states"]["initial"]["terms"]))
+        for k, v in sums.items():
+            np.testing.assert_allclose(float(v), ref[k], rtol=1e-9, atol=1e-12)
