@@ -138,6 +138,41 @@ class ShardedFitter:
             self._coll = (ctypes.cast(cb, ctypes.c_void_p).value, None, cb, "host callback (%s)" % backend_name)
         return self._coll
 
+    def prove_world(self):
+        """-> dict for a benchmark line / a test: what the collective the sharded loop uses really spans.  Every rank puts
+        (rank + 1) into the first float of its record and the function pointer handed to smalfit_shard_run gathers it -- the same
+        native ncclAllGather call on the same communicator and stream, or the same host callback -- and the result must be
+        1 .. world in rank order.  With the native path the communicator itself is also asked for its size and this rank's index
+        (ncclCommCount / ncclCommUserRank through the library instance torch loaded)."""
+        fn, ctx, keep, kind = self._collective()
+        flat = getattr(self.fitter, "flat", None)
+        dev = flat.device if flat is not None else torch.device("cpu")
+        send = torch.zeros(4, device=dev, dtype=torch.float32)
+        send[0] = float(self.rank + 1)
+        recv = torch.zeros(self.world, 4, device=dev, dtype=torch.float32)
+        rc = 0
+        if kind == "rccl":
+            call = ctypes.cast(ctypes.c_void_p(fn), _lib.ALLGATHER_FN)
+            rc = call(ctx, send.data_ptr(), recv.data_ptr(), 4, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+        else:
+            dist.all_gather_into_tensor(recv.view(-1), send, group=self.group)
+        stamps = [int(round(float(v))) for v in recv[:, 0].cpu()]
+        out = {"collective": kind, "world_size": self.world, "rank_stamps": stamps, "rc": int(rc),
+               "distinct_ranks": len(set(stamps)), "ok": rc == 0 and stamps == list(range(1, self.world + 1))}
+        if kind == "rccl":
+            try:
+                rccl = ctypes.CDLL(_loaded_library("librccl"))
+                cnt, me = ctypes.c_int(-1), ctypes.c_int(-1)
+                comm = ctypes.c_void_p(keep.comm)
+                rccl.ncclCommCount(comm, ctypes.byref(cnt))
+                rccl.ncclCommUserRank(comm, ctypes.byref(me))
+                out["ncclCommCount"], out["ncclCommUserRank"] = cnt.value, me.value
+                out["ok"] = out["ok"] and cnt.value == self.world and me.value == self.rank
+            except (OSError, AttributeError) as exc:
+                out["ncclCommCount_error"] = str(exc)
+        return out
+
     def _buffers(self):
         f = self.fitter
         ns = f.num_shared()

@@ -38,6 +38,8 @@ PARAMS = ("betas", "log_beta_scales", "global_rotation", "joint_rotations", "tra
 CASES = {
     "crop8": dict(frames=8, image_size=256, window=8, dz=1.2, states=("initial", "hip_stage1", "hip_final", "near_gt")),
     "config3": dict(frames=64, image_size=256, window=8, dz=0.0, states=("initial", "hip_stage1", "near_gt")),
+    # targets only (bench.py's second scene, `value_crop`): 64 frames of the crop-filling scene, rendered by the oracle
+    "crop64": dict(frames=64, image_size=256, window=8, dz=1.2, states=()),
 }
 STATE_STAGE = {"initial": 1, "hip_stage1": 2, "hip_final": 3, "near_gt": 3}      # whose weight column a state is evaluated with
 HIP_STATE_AFTER = {"hip_stage1": 2, "hip_final": 4}                              # number of completed stages

@@ -10,6 +10,7 @@ reference output.  Hours of CPU: run in the build container, one process per pre
 
     python tests/golden/make_oracle_config2.py f64 [threads]      (about 1.5-2 h on 3 threads)
     python tests/golden/make_oracle_config2.py f32 [threads]
+    python tests/golden/make_oracle_config2.py f32b [threads]     (a second float32 draw: initial translation moved by 1e-7)
     python tests/golden/make_oracle_config2.py heads [threads]    (after f64: minutes; see heads())
 
 Progress is checkpointed to /tmp/oracle_config2_<tag>.ckpt every 25 iterations (rerun to continue) and a partial fixture
@@ -85,10 +86,16 @@ def main():
         torch.set_num_threads(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
         return heads()
     torch.set_num_threads(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
-    dtype = {"f64": torch.float64, "f32": torch.float32}[tag]
+    # f32b: a SECOND float32 draw -- the same float32 oracle loop from an initial translation moved by 1e-7 (one unit in the last
+    # place of 1.0) -- because a float32 trajectory of ~2000 Adam steps is ONE sample of a chaotic map: the yardstick of a comparison
+    # with the float64 run is the largest deviation any recorded float32 draw shows (tests/test_gpu_config2.py)
+    dtype = {"f64": torch.float64, "f32": torch.float32, "f32b": torch.float32}[tag]
     md, tg = c2.targets()
     start = c2.initial_params()
     fp = c2.fingerprint(tg, start)
+    if tag == "f32b":
+        start = {k: v.copy() for k, v in start.items()}
+        start["trans"][:, 0] += np.float32(1e-7)
     prob = c2.problem(md, tg, dtype)
     ckpt = "/tmp/oracle_%s_%s.ckpt" % (c2.name, tag)
     state = None

@@ -122,6 +122,8 @@ def _worker(rank, world, port, out_q, N=4, window=2):
                 f.step(W[0][:6], float(W[stage_id][6]), float(W[stage_id][8]), stage_id)
         else:                    # ... and a whole stage at once (one library call with the HIP engine; a loop over step() for a
             f.run_iterations(w1, float(W[stage_id][6]), float(W[stage_id][8]), stage_id, its)    # local fitter without shard_run)
+    proof = f.prove_world()                 # what bench.py --gpus N puts into its line: the collective spans `world` distinct ranks
+    assert proof["ok"] and proof["rank_stamps"] == list(range(1, world + 1)) and proof["distinct_ranks"] == world, proof
     out_q.put((rank, (lo, hi), {k: v.numpy() for k, v in f.fitter.p.items()}))
     dist.barrier()
     dist.destroy_process_group()

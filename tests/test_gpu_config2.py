@@ -17,7 +17,10 @@ What is asserted, and why these bounds:
         the last float32 bit becomes a +-lr step), so float32 arithmetic alone carries ANY implementation away from the
         float64 run.  The yardstick is the oracle itself run in float32 (oracle_config2_f32.npz): per parameter tensor,
         ||HIP - f64|| <= DRIFT_FACTOR x (the largest ||f32 oracle - f64|| at any stage end so far) AND
-        <= SAME_STAGE_FACTOR x ||f32 oracle - f64|| at the same stage end, at the end of every stage and of the run.
+        <= SAME_STAGE_FACTOR x ||f32 oracle - f64|| at the same stage end, at the end of every stage and of the run;
+        "the float32 oracle" = the largest value over its recorded draws (round 5: config 1 carries a second draw, `f32b`, the
+        same loop from an initial translation moved by one unit in the last place -- a single image's translation is three
+        numbers, and its deviation in ONE float32 trajectory is anything between 6e-5 and 6e-4 from one stage end to the next).
 The tables are printed past pytest's capture, so the driver's log of the GPU run shows them.
 """
 import numpy as np
@@ -64,7 +67,7 @@ def case(request):
 
     import os
     heads = np.load(c2.fixture_path("heads"), allow_pickle=False) if os.path.exists(c2.fixture_path("heads")) else None
-    return dict(c2=c2, f64=f64, f32=c2.load_fixture("f32"), heads=heads, new_fitter=new_fitter, W=np.array(cfg.OPT_WEIGHTS).T, e=e)
+    return dict(c2=c2, f64=f64, f32=c2.load_fixture("f32"), f32_more=[d for d in (c2.load_fixture("f32b"),) if d is not None and d["complete"]], heads=heads, new_fitter=new_fitter, W=np.array(cfg.OPT_WEIGHTS).T, e=e)
 
 
 def test_fixture_matches_the_problem(case):
@@ -133,8 +136,11 @@ def test_full_schedule_end_state_within_the_float32_yardstick(case, capsys):
         if not ref64 or not ref32:
             continue
         checked += 1
+        # every recorded float32 draw of the oracle (f32; f32b = the same loop from an initial translation moved by 1e-7, when the
+        # fixture exists): one float32 trajectory is ONE sample of a chaotic map, the yardstick is the largest deviation any draw shows
+        draws = [ref32] + [(d["stage_start"].get(stage + 1) if stage < 3 else d["final"]) for d in case["f32_more"]]
         for k in c2.PARAMS:
-            hip, yard = _rel(ends[stage][0][k], ref64[k]), _rel(ref32[k], ref64[k])
+            hip, yard = _rel(ends[stage][0][k], ref64[k]), max(_rel(d[k], ref64[k]) for d in draws)
             yard_max[k] = max(yard_max[k], yard)
             lines.append("%s, end of stage %d, %-16s rel-L2: HIP vs f64 %.2e   f32 oracle vs f64 %.2e (x%.2f; so far %.2e)"
                          % (c2.name, stage, k, hip, yard, hip / max(yard, 1e-30), yard_max[k]))
@@ -151,10 +157,11 @@ def test_full_schedule_end_state_within_the_float32_yardstick(case, capsys):
         # final per-term losses: the last trace row is the evaluation BEFORE the last update, like FusedFitter.losses
         ref, ref32 = f64["trace"][-1], f32["trace"][-1]
         hip = ends[3][1][:8]
+        all32 = [ref32] + [d["trace"][-1] for d in case["f32_more"]]
         # a single term's deviation is ONE draw of a chaotic trajectory (the ratio of two such draws is heavy-tailed: the same
         # engine with another band policy moved the silhouette term from 1.5 x to 2.0 x the float32 oracle's own): the yardstick
         # for every term is what the float32 oracle's terms deviate by ALTOGETHER (absolute), not that term's own draw
-        yard_abs = float(np.sum(np.abs(ref32 - ref)))
+        yard_abs = max(float(np.sum(np.abs(r32 - ref))) for r32 in all32)
         for i, name in enumerate(c2.TERMS):
             d = abs(hip[i] - ref[i])
             with capsys.disabled():
@@ -164,7 +171,7 @@ def test_full_schedule_end_state_within_the_float32_yardstick(case, capsys):
         # the total: the float32 oracle's term deviations happen to cancel (6e-5 of the total from terms off by 2e-4 .. 4e-3 each); the
         # yardstick is what they add up to without cancellation
         dt, yt = abs(hip.sum() - ref.sum()) / ref.sum(), abs(ref32.sum() - ref.sum()) / ref.sum()
-        ysum = float(np.sum(np.abs(ref32 - ref))) / ref.sum()
+        ysum = yard_abs / ref.sum()
         with capsys.disabled():
             print("%s, final total: HIP %.6f  f64 %.6f  rel %.2e   (f32 oracle rel %.2e; sum of its |term deviations| %.2e)"
                   % (c2.name, hip.sum(), ref.sum(), dt, yt, ysum))
