@@ -60,7 +60,9 @@ typedef struct smalfit_model_desc {
 int smalfit_model_create(const smalfit_model_desc* desc, smalfit_model** out);
 void smalfit_model_destroy(smalfit_model* model);
 
-/* ---- engine = workspace in HBM for up to max_frames frames at image_size^2 ---------------------- */
+/* ---- engine = workspace in HBM for up to max_frames frames at image_size^2 ----------------------
+ * image_size <= 1024 (the reference renders 256 or 512, config.py IMG_RES; larger sizes are rejected: the rasteriser's
+ * pixel walk is exact in float32 up to there) */
 int smalfit_engine_create(smalfit_model* model, int max_frames, int image_size, smalfit_engine** out);
 void smalfit_engine_destroy(smalfit_engine* engine);
 /* synchronises `stream`, returns and clears the sticky status bits (SMALFIT_STATUS_*) */

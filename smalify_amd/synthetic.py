@@ -41,7 +41,7 @@ def load_synth_mesh():
     return m["verts"].astype(np.float64), m["faces"].astype(np.int64), m["sym_idx"].astype(np.int64)
 
 
-def synthetic_smal_dicts(seed=0, dense_weights=False):
+def synthetic_smal_dicts(seed=0, dense_weights=False, symmetric_basis=False):
     """-> (dd, data, sym_idx) in the reference's pickle layout.
 
     dd   : f (F,3) uint32, v_template (V,3) f64, shapedirs (V,3,41) f64, posedirs (V,3,306) f64,
@@ -49,6 +49,10 @@ def synthetic_smal_dicts(seed=0, dense_weights=False):
     data : cluster_means (5,41), cluster_cov list of 5 (41,41) SPD
     dense_weights: every vertex gets a non-zero weight for every joint (stress variant); the default
            follows rigged-mesh practice: <= 4 influences per vertex, sparse joint regressor.
+    symmetric_basis: the shape basis is made mirror-symmetric about the y = 0 plane (like a real SMAL model's): every family mean
+           then leaves the template left/right balanced, so ALL five shape families load (with the default basis families 2
+           and 3 stop where the reference stops, smal_basics.py:32-35).  The default stays as it was: the golden fixtures
+           belong to it.
     """
     import scipy.sparse as sp
 
@@ -63,6 +67,10 @@ def synthetic_smal_dicts(seed=0, dense_weights=False):
     for b in range(41):
         coef = rs.randn(10, 3) * np.array([0.3, 1, 1, 1, 2, 2, 2, 2, 2, 2])[:, None]
         shapedirs[:, :, b] = (basis @ coef) * (0.035 / (1.0 + 0.15 * b))
+
+    if symmetric_basis:
+        mirror = np.array([1.0, -1.0, 1.0])[None, :, None]
+        shapedirs = 0.5 * (shapedirs + mirror * shapedirs[sym_idx])      # centre vertices (sym_idx[v] = v): no y displacement
 
     # --- pose-corrective basis: dense, small ------------------------------------------------------
     posedirs = rs.randn(nv, 3, topo.NUM_POSE_FEATURES) * 0.004

@@ -547,12 +547,11 @@ def case_config5_fit(family, M=2, S=512, window=2, iters=2, seed=47, z=1.9):
     stage = 2
     weights, w_temp, lr = W[stage][:6].copy(), float(W[stage][6]), float(W[stage][8])
     unity = family == 1
-    dd, data, sym = synthetic.synthetic_smal_dicts(seed=0)
-    # the synthetic stand-in's shape basis is not mirror-symmetric: adding the cluster mean of family 2 or 3 leaves the template
-    # with unequal left / right vertex counts, where the reference stops (smal_basics.py:32-35) and so does prepare_model.  Those
-    # two families are exercised through THEIR cluster priors (what distinguishes the fitters of a mixed batch on the fitting
-    # path) on the family-0 mesh; the family-dependent template itself is covered by families 0 and 1.
-    mdf = model_io.prepare_model(dd, data, sym, family if family in (0, 1) else 0)
+    # the stand-in's shape basis made mirror-symmetric like a real SMAL model's (round 5): every family's cluster mean then leaves
+    # the template left / right balanced and all four families load through prepare_model, each with ITS template and ITS prior
+    # (with the default basis families 2 and 3 stop where the reference stops, smal_basics.py:32-35)
+    dd, data, sym = synthetic.synthetic_smal_dicts(seed=0, symmetric_basis=True)
+    mdf = model_io.prepare_model(dd, data, sym, family)
     om = so.OracleModel(mdf)
     dm = eng.DeviceModel(mdf)
     e = eng.Engine(dm, M, S)

@@ -211,10 +211,11 @@ def test_fit_single_image_configuration():
 def test_config5_short_fit_every_shape_family_at_512(family):
     """BASELINE config 5 (mixed shape-family batch, 512 x 512, limb scales on) is a set of independent fitters, one per family:
     each family's fitter -- cat / canine / equine / bovine; the unity-style prior with shared scales for family 1, the SMAL
-    cluster prior with per-frame trained limb scales for the others (one evaluation of family 0 at 512 x 512 used to be a test
-    of its own; this fit includes it) -- follows the oracle loop (losses, analytic gradients, Adam) for two stage-2
+    cluster prior with per-frame trained limb scales for the others, every family on ITS OWN template (the stand-in's shape basis made
+    mirror-symmetric like a real SMAL model's, so that all family means load: synthetic_smal_dicts(symmetric_basis=True)), all at
+    512 x 512 -- follows the oracle loop (losses, analytic gradients, Adam) for two stage-2
     iterations within north_star's 1e-4 (the oracle needs ~10 s per 512 x 512 iteration: more would dominate the suite)"""
-    m = pc.case_config5_fit(family, S=512 if family < 2 else 256)     # families 2 / 3 differ by their priors only: a smaller image
+    m = pc.case_config5_fit(family, S=512)
     print("config 5, family %d: %s" % (family, {k: ("%.2e" % v if isinstance(v, float) else v) for k, v in m.items()}))
     assert m["status"] == 0 and m["sil_oracle"] > 0.0
     assert m["loss_rel_max"] < 1e-4, m

@@ -5,7 +5,7 @@
 tag=${1:-rX}
 cd $GRAFT_REPO_ROOT
 out=gpurun_out
-timeout 600 python -m pytest tests -q -m gpu 2>&1 | tee $out/${tag}_gpu_tests.log | tail -25
+timeout 1200 python -m pytest tests -q -m gpu 2>&1 | tee $out/${tag}_gpu_tests.log | tail -40
 timeout 240 python bench.py > $out/${tag}_bench_default.json 2> $out/${tag}_bench_default.err
 timeout 120 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/${tag}_bench_20_driver_args.json 2>> $out/${tag}_bench_default.err
 timeout 90 python bench.py --steps 1950 --no-cpu-baseline --no-crop > $out/${tag}_bench_1950_survey.json 2>> $out/${tag}_bench_default.err
@@ -14,6 +14,9 @@ SMALFIT_BENCH_FORCE_DIST=1 timeout 120 python -m torch.distributed.run --nnodes=
 for n in 1 2 4 8; do timeout 100 python tools/rank_sim.py $n 390 2>&1 | tail -1; done > $out/${tag}_rank_sim.txt
 bash tools/prof_stats.sh ${tag}_390 390 survey > $out/${tag}_prof390.log 2>&1
 timeout 250 python tools/pmc_sq.py ${tag}_pmc > $out/${tag}_pmc.log 2>&1
+PMC_SCRIPT="tools/crop_fit.py crop 0.3" timeout 250 python tools/pmc_sq.py ${tag}_pmc_crop > $out/${tag}_pmc_crop.log 2>&1
+bash tools/prof_cmd.sh ${tag}_crop python tools/crop_fit.py crop 1.0 > $out/${tag}_prof_crop.log 2>&1
+bash tools/prof_cmd.sh ${tag}_8frames python tools/rank_sim.py 8 390 > $out/${tag}_prof_8frames.log 2>&1
 ( cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/trace20; timeout 100 rocprofv3 --kernel-trace --output-format csv -d /tmp/trace20 -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-crop > /dev/null 2>&1; f=$(find /tmp/trace20 -name "*kernel_trace.csv" | head -1); python $GRAFT_REPO_ROOT/tools/trace_window.py $f 20 cold > $GRAFT_REPO_ROOT/$out/${tag}_trace20_cold.txt; python $GRAFT_REPO_ROOT/tools/trace_gaps.py $f 20 > $GRAFT_REPO_ROOT/$out/${tag}_trace20_gaps.txt )
 for f in bench_default bench_20_driver_args bench_1950_survey bench_1950_crop bench_rccl_world1; do python - <<PY
 import json
