@@ -5,7 +5,7 @@
 tag=${1:-rX}
 cd $GRAFT_REPO_ROOT
 out=gpurun_out
-timeout 1200 python -m pytest tests -q -m gpu 2>&1 | tee $out/${tag}_gpu_tests.log | tail -40
+if [ "$2" != "notests" ]; then timeout 1200 python -m pytest tests -q -m gpu 2>&1 | tee $out/${tag}_gpu_tests.log | tail -40; fi
 timeout 240 python bench.py > $out/${tag}_bench_default.json 2> $out/${tag}_bench_default.err
 timeout 120 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/${tag}_bench_20_driver_args.json 2>> $out/${tag}_bench_default.err
 timeout 90 python bench.py --steps 1950 --no-cpu-baseline --no-crop > $out/${tag}_bench_1950_survey.json 2>> $out/${tag}_bench_default.err
@@ -18,6 +18,12 @@ PMC_SCRIPT="tools/crop_fit.py crop 0.3" timeout 250 python tools/pmc_sq.py ${tag
 bash tools/prof_cmd.sh ${tag}_crop python tools/crop_fit.py crop 1.0 > $out/${tag}_prof_crop.log 2>&1
 bash tools/prof_cmd.sh ${tag}_8frames python tools/rank_sim.py 8 390 > $out/${tag}_prof_8frames.log 2>&1
 ( cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/trace20; timeout 100 rocprofv3 --kernel-trace --output-format csv -d /tmp/trace20 -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-crop > /dev/null 2>&1; f=$(find /tmp/trace20 -name "*kernel_trace.csv" | head -1); python $GRAFT_REPO_ROOT/tools/trace_window.py $f 20 cold > $GRAFT_REPO_ROOT/$out/${tag}_trace20_cold.txt; python $GRAFT_REPO_ROOT/tools/trace_gaps.py $f 20 > $GRAFT_REPO_ROOT/$out/${tag}_trace20_gaps.txt )
+# gpurun copies back at most 64 MiB: keep the summaries, drop the raw per-dispatch tables
+rm -rf $out/${tag}_pmc/g[0-9] $out/${tag}_pmc_crop/g[0-9] $out/${tag}_pmc/counters_list.txt $out/${tag}_pmc_crop/counters_list.txt
+for d in $out/prof_${tag}_390 $out/prof_${tag}_crop $out/prof_${tag}_8frames; do
+  f=$(find $d -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $d.kernel_stats.csv; rm -rf $d
+done
+du -sh $out | tail -1
 for f in bench_default bench_20_driver_args bench_1950_survey bench_1950_crop bench_rccl_world1; do python - <<PY
 import json
 try:
