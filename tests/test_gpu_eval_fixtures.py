@@ -56,7 +56,7 @@ def _setup(case):
 
 
 @pytest.mark.parametrize("case", ["crop8", "config3"])
-def test_losses_and_gradients_match_the_float64_oracle(case):
+def test_losses_and_gradients_match_the_float64_oracle(case, capsys):
     ec, fx, e, fitter_at = _setup(case)
     assert set(fx["states"]) >= {"initial", "near_gt"}
     lines, bad = [], []
@@ -90,12 +90,12 @@ def test_losses_and_gradients_match_the_float64_oracle(case):
                 if err > max(GRAD_TOL, YARD * (y if y == y else 0.0)):
                     bad.append(lines[-1])
         assert e.status() == 0
-    sys.__stdout__.write("\n[eval fixtures: HIP vs float64 oracle]\n" + "\n".join(lines) + "\n")
-    sys.__stdout__.flush()
+    with capsys.disabled():
+        print("\n[eval fixtures: HIP vs float64 oracle]\n" + "\n".join(lines))
     assert not bad, "\n".join(bad)
 
 
-def test_crop_states_run_the_large_face_paths():
+def test_crop_states_run_the_large_face_paths(capsys):
     """the crop8 states the fixture holds really are the regime it is there for: thousands of faces whose pixel boxes exceed
     256 pixels (no byte candidate list: kernels_raster.inc `listed`, box-walking backward) and boxes far larger than the
     sweep's 32 x 32 LDS window.  Boxes are recomputed on the host from the vertices the evaluation hands out
@@ -119,9 +119,9 @@ def test_crop_states_run_the_large_face_paths():
         big += int((px > 256).sum())
         wide += int((px > 1024).sum())
     rows = (sil > 0.5).any(2).sum(1).float().mean().item()
-    sys.__stdout__.write("\n[crop8 %s] faces with boxes > 256 px: %d of %d, > 1024 px: %d; silhouette spans %.0f of %d rows\n"
-                         % (name, big, N * len(faces), wide, rows, S))
-    sys.__stdout__.flush()
+    with capsys.disabled():
+        print("\n[crop8 %s] faces with boxes > 256 px: %d of %d, > 1024 px: %d; silhouette spans %.0f of %d rows"
+              % (name, big, N * len(faces), wide, rows, S))
     assert big >= 0.02 * N * len(faces), big
     assert wide > 0
     assert rows > 0.5 * S
