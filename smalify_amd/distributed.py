@@ -168,7 +168,7 @@ class ShardedFitter:
                 rccl.ncclCommCount(comm, ctypes.byref(cnt))
                 rccl.ncclCommUserRank(comm, ctypes.byref(me))
                 out["ncclCommCount"], out["ncclCommUserRank"] = cnt.value, me.value
-                out["ok"] = out["ok"] and cnt.value == self.world and me.value == self.rank
+                out["communicator_agrees"] = cnt.value == self.world and me.value == self.rank     # reported; `ok` is the gathered stamps
             except (OSError, AttributeError) as exc:
                 out["ncclCommCount_error"] = str(exc)
         return out
