@@ -125,3 +125,63 @@ def test_crop_states_run_the_large_face_paths(capsys):
     assert big >= 0.02 * N * len(faces), big
     assert wide > 0
     assert rows > 0.5 * S
+
+
+def test_config4_shards_add_up_to_the_oracle_at_full_size(capsys):
+    """BASELINE config 4 at its own size, oracle-backed: the 64-frame 256 x 256 sequence split 8 frames per rank (WINDOW 8) -- here the
+    eight shards of `config3`'s fixture evaluated one after the other on one GPU, each a FusedFitter that is told where its frames sit in
+    the sequence (frame_offset / total_frames) and holds its neighbours' boundary frames as halos, exactly what a rank of the sharded loop
+    evaluates (smalify_amd/distributed.py; the collective only moves these records).  The ranks' loss terms must add up to the float64
+    oracle's terms of the WHOLE sequence, the per-frame gradients concatenated and the partial shape gradients summed over the ranks must be
+    its gradients -- at the HIP fit's own state after stage 1, with stage 2's weights (silhouette and temporal terms on)."""
+    ec, fx, _, _ = _setup("config3")
+    from smalify_amd import distributed, engine as eng, fitter as fit, synthetic
+    tg = ec.load_targets("config3")
+    c = ec.CASES["config3"]
+    N, world = c["frames"], 8
+    st = fx["states"]["hip_stage1"]
+    weights, w_temp, _ = ec.stage_weights(st["stage"])
+    md = synthetic.synthetic_model(seed=0, shape_family_id=1)
+    e = eng.Engine(eng.DeviceModel(md), N // world, c["image_size"])
+    e.set_pose_prior(*synthetic.synthetic_pose_prior())
+    e.set_shape_prior(*synthetic.synthetic_shape_prior())
+    P = st["params"]
+    fitters = []
+    for r in range(world):
+        lo, hi = distributed.shard_range(N, r, world, c["window"])
+        f = fit.FusedFitter(e, tg["tj"][lo:hi], tg["vis"][lo:hi], tg["tsil"][lo:hi].astype(np.float32), c["window"], True, P["betas"],
+                            P["log_beta_scales"], frame_offset=lo, total_frames=N)
+        for k in ("global_rotation", "joint_rotations", "trans"):
+            f.p[k].copy_(torch.as_tensor(np.asarray(P[k][lo:hi], np.float32)).cuda().reshape(f.p[k].shape))
+        fitters.append((lo, hi, f))
+    recs = [f.boundary_records().clone() for _, _, f in fitters]           # (2, 108): first and last frame of every shard
+    terms = np.zeros(8)
+    grads = {k: np.zeros_like(np.asarray(st["grads"][k], np.float64)) for k in st["grads"]}
+    for r, (lo, hi, f) in enumerate(fitters):
+        f.halo_prev = recs[r - 1][1].contiguous() if r > 0 else None
+        f.halo_next = recs[r + 1][0].contiguous() if r + 1 < world else None
+        e.reset_raster_cache()
+        f.evaluate(weights, w_temp, st["stage"])
+        terms += f.losses.cpu().numpy().astype(np.float64)[:8]
+        for k in grads:
+            g = f.g[k].cpu().numpy().astype(np.float64)
+            if k in ("betas", "log_beta_scales"):
+                grads[k] += g.reshape(grads[k].shape)                  # partial shape gradients: summed over the ranks
+            else:
+                grads[k][lo:hi] = g.reshape(grads[k][lo:hi].shape)
+        assert e.status() == 0
+    ref = st["terms"]
+    lines, bad = [], []
+    for i, t in enumerate(ec.TERMS):
+        err = abs(terms[i] - ref[i]) / max(abs(ref[i]), 1e-3 * abs(ref.sum()))
+        lines.append("config4 (8 shards of 8)  %-11s sum over ranks %.8g  f64 oracle %.8g  rel %.2e" % (t, terms[i], ref[i], err))
+        if err > TERM_TOL:
+            bad.append(lines[-1])
+    for k, g in st["grads"].items():
+        err, y = _rel(grads[k], g), _rel(st["grads_f32"][k], g)
+        lines.append("config4 (8 shards of 8)  d/d%-16s rel-L2 %.2e  (f32 oracle %.2e)" % (k, err, y))
+        if err > max(GRAD_TOL, YARD * y):
+            bad.append(lines[-1])
+    with capsys.disabled():
+        print("\n" + "\n".join(lines))
+    assert not bad, "\n".join(bad)
