@@ -89,13 +89,16 @@ def main():
     # f32b: a SECOND float32 draw -- the same float32 oracle loop from an initial translation moved by 1e-7 (one unit in the last
     # place of 1.0) -- because a float32 trajectory of ~2000 Adam steps is ONE sample of a chaotic map: the yardstick of a comparison
     # with the float64 run is the largest deviation any recorded float32 draw shows (tests/test_gpu_config2.py)
-    dtype = {"f64": torch.float64, "f32": torch.float32, "f32b": torch.float32}[tag]
+    # (f32c / f32d / f32e: further draws -- y + 1e-7, z + 1e-7, x - 1e-7)
+    DRAWS = {"f32b": (0, 1e-7), "f32c": (1, 1e-7), "f32d": (2, 1e-7), "f32e": (0, -1e-7)}
+    dtype = torch.float64 if tag == "f64" else torch.float32
+    assert tag in ("f64", "f32") or tag in DRAWS, tag
     md, tg = c2.targets()
     start = c2.initial_params()
     fp = c2.fingerprint(tg, start)
-    if tag == "f32b":
+    if tag in DRAWS:
         start = {k: v.copy() for k, v in start.items()}
-        start["trans"][:, 0] += np.float32(1e-7)
+        start["trans"][:, DRAWS[tag][0]] += np.float32(DRAWS[tag][1])
     prob = c2.problem(md, tg, dtype)
     ckpt = "/tmp/oracle_%s_%s.ckpt" % (c2.name, tag)
     state = None

@@ -71,7 +71,7 @@ def case(request):
 
     import os
     heads = np.load(c2.fixture_path("heads"), allow_pickle=False) if os.path.exists(c2.fixture_path("heads")) else None
-    return dict(c2=c2, f64=f64, f32=c2.load_fixture("f32"), f32_more=[d for d in (c2.load_fixture("f32b"),) if d is not None and d["complete"]], heads=heads, new_fitter=new_fitter, W=np.array(cfg.OPT_WEIGHTS).T, e=e)
+    return dict(c2=c2, f64=f64, f32=c2.load_fixture("f32"), f32_more=[d for d in (c2.load_fixture(t) for t in ("f32b", "f32c", "f32d", "f32e")) if d is not None and d["complete"]], heads=heads, new_fitter=new_fitter, W=np.array(cfg.OPT_WEIGHTS).T, e=e)
 
 
 def test_fixture_matches_the_problem(case):
