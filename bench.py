@@ -423,6 +423,10 @@ def main():
                 out_i = {"valu_insts_per_launch": row["SQ_INSTS_VALU"], "salu_insts_per_launch": row.get("SQ_INSTS_SALU"),
                          "blended_cycles_per_valu": cpi, "simds": NUM_SIMDS, "clock_ghz": PEAK_CLOCK_GHZ, "launch_ms": launch_ms,
                          "frac": row["SQ_INSTS_VALU"] * cpi / cycles,
+                         "achieved_cycles_per_valu": cycles / row["SQ_INSTS_VALU"],
+                         "frac_note": "modelled issue cycles (static instruction mix x issue costs measured in isolation) over the cycles available at the nominal "
+                                      "peak clock: an estimate good to ~10 %, so a kernel at its issue ceiling reads 0.9-1.05; `achieved_cycles_per_valu` is the "
+                                      "model-free figure (2.6 = every instruction a full-rate one)",
                          "lds_bank_conflict_per_active": (row["SQ_LDS_BANK_CONFLICT"] / row["SQ_LDS_IDX_ACTIVE"]) if row.get("SQ_LDS_IDX_ACTIVE") else None,
                          "wait_share_of_wave_cycles": (row["SQ_WAIT_ANY"] / row["SQ_WAVE_CYCLES"]) if row.get("SQ_WAVE_CYCLES") else None,
                          "traffic_ratio": traffic_ / algo if algo else None}
