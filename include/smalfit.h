@@ -35,8 +35,9 @@ typedef struct smalfit_engine smalfit_engine;
  * tail from version to version.  History: 1 = round 1; 2 = 9 loss terms (losses must hold SMALFIT_NUM_LOSS_TERMS floats),
  * smalfit_fit_args gained target_sil_u8 / w_limit; 3 = smalfit_fit_args.struct_size (first field), frame_offset,
  * total_frames; smalfit_engine_clear_joint_limits, smalfit_shard_local_step; 4 = smalfit_shard_run (the sharded loop of a
- * whole stage in one call, the collective supplied by the host as a function pointer), smalfit_rccl_allgather. */
-#define SMALFIT_ABI_VERSION 4
+ * whole stage in one call, the collective supplied by the host as a function pointer), smalfit_rccl_allgather;
+ * 5 = smalfit_engine_set_option. */
+#define SMALFIT_ABI_VERSION 5
 int smalfit_version(void);
 const char* smalfit_last_error(void);
 
@@ -98,6 +99,16 @@ int smalfit_engine_set_pose_prior(smalfit_engine* engine, const float* prec, con
 int smalfit_engine_set_joint_limits(smalfit_engine* engine, const float* min_values, const float* max_values);
 /* back to the reference's behaviour (term commented out): w_limit is ignored again */
 int smalfit_engine_clear_joint_limits(smalfit_engine* engine);
+/* Engine options (no counterpart in the reference: they select between readings of pytorch3d 0.2.5 that cannot be told apart
+ * without a PyTorch3D-produced vector).
+ *   SMALFIT_OPT_UNCLAMPED_EDGE_T  value 0 (default) / 1.  replaces: rasterize_meshes_backward behind
+ *     MeshRasterizer / SoftSilhouetteShader, reference smal_fitter/p3d_renderer.py:33-39.  0 = the exact gradient of the
+ *     forward's point-segment distance (edge parameter t clamped to [0, 1]); 1 = the gradient with t left unclamped (the edge
+ *     treated as an infinite line in PointLineDistanceBackward), as some 0.2.x sources are recalled to do.  The two differ only
+ *     at pixels whose nearest feature of the nearest edge is a vertex.  Applies to smalfit_fit_eval / smalfit_fit_run /
+ *     smalfit_shard_run / smalfit_render_backward; the forward pass is the same either way. */
+#define SMALFIT_OPT_UNCLAMPED_EDGE_T 1
+int smalfit_engine_set_option(smalfit_engine* engine, int option, int value);
 /* replaces: betas_prec / mean_betas          reference smal_fitter/smal_fitter.py:48-69
  * host arrays: prec (dim,dim), mean (dim); dim = 26 (unity prior: betas|log scales) or <= 20 */
 int smalfit_engine_set_shape_prior(smalfit_engine* engine, const float* prec, const float* mean, int dim);

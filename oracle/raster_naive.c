@@ -8,7 +8,9 @@
  *     barycentrics (area + kEpsilon), depth test pz >= 0, squared point-triangle distance,
  *     keep the K = faces_per_pixel nearest in depth           
  *   - sigmoid_alpha_blend: alpha = prod_k (1 - sigmoid(-d_k / sigma)), silhouette = 1 - alpha
- *   - backward: exact gradient of the forward (distance through the nearest edge with clamped t)
+ *   - backward: exact gradient of the forward (distance through the nearest edge with clamped t); with unclamped_t != 0 the
+ *     gradient with t left unclamped instead (last row: what some 0.2.x sources are recalled to do in
+ *     PointLineDistanceBackward) -- same forward, same nearest edge (first minimum: a-b, a-c, b-c)
  * "parity unpinned": no vector produced by pytorch3d itself is available (see oracle/smal_oracle.py).
  *
  * Build: gcc -O2 -shared -fPIC oracle/raster_naive.c -o oracle/_build/libraster_naive.so -lm
@@ -23,15 +25,18 @@ static float edge_fn(float px, float py, float ux, float uy, float wx, float wy)
   return (px - ux) * (wy - uy) - (py - uy) * (wx - ux);
 }
 
-/* squared distance point -> segment (u,w); also returns clamped t and which end is degenerate */
+/* squared distance point -> segment (u,w); also returns clamped t (and the unclamped one; a degenerate edge: its end point w, t = 1) */
+static float t_raw_last;
 static float seg_dist2(float px, float py, float ux, float uy, float wx, float wy, float* t_out) {
   const float ex = wx - ux, ey = wy - uy;
   const float l2 = ex * ex + ey * ey;
   if (l2 <= K_EPS) {
     *t_out = 1.0f;
+    t_raw_last = 1.0f;
     return (px - wx) * (px - wx) + (py - wy) * (py - wy);
   }
   float t = ((px - ux) * ex + (py - uy) * ey) / l2;
+  t_raw_last = t;
   if (t < 0.0f) t = 0.0f;
   if (t > 1.0f) t = 1.0f;
   *t_out = t;
@@ -112,7 +117,7 @@ void raster_naive_forward(const float* v, int V, const int* faces, int F, int S,
 /* gradient of sum(grad_sil * sil) with respect to the 2-D NDC vertex positions: gv (V,2), zero-initialised
  * by the caller.  Uses the fragments (p2f, dists) of the forward. */
 void raster_naive_backward(const float* v, const int* faces, int S, int K, float sigma, const int* p2f,
-                           const float* dists, const float* grad_sil, double* gv) {
+                           const float* dists, const float* grad_sil, double* gv, int unclamped_t) {
   for (int yi = 0; yi < S; ++yi) {
     const float yf = 1.0f - (2.0f * (float)yi + 1.0f) / (float)S;
     for (int xi = 0; xi < S; ++xi) {
@@ -136,7 +141,7 @@ void raster_naive_backward(const float* v, const int* faces, int S, int K, float
         for (int e = 0; e < 3; ++e) {
           float t;
           const float d = seg_dist2(xf, yf, v[3 * idx[e][0]], v[3 * idx[e][0] + 1], v[3 * idx[e][1]], v[3 * idx[e][1] + 1], &t);
-          if (e == 0 || d < bd) { bd = d; bt = t; best = e; }
+          if (e == 0 || d < bd) { bd = d; bt = unclamped_t ? t_raw_last : t; best = e; }
         }
         const int iu = idx[best][0], iw = idx[best][1];
         const double qx = (double)xf - ((double)v[3 * iu] + bt * ((double)v[3 * iw] - v[3 * iu]));

@@ -44,8 +44,9 @@ def forward(v_ndc, faces, S, K=100, sigma=SIGMA, blur=BLUR, want_fragments=True)
     return sil, p2f, zbuf, dists, maxc.value
 
 
-def backward(v_ndc, faces, S, p2f, dists, grad_sil, K=100, sigma=SIGMA):
-    """-> d(sum grad_sil*sil)/d(v_ndc[:, :2])  (V,2) float64"""
+def backward(v_ndc, faces, S, p2f, dists, grad_sil, K=100, sigma=SIGMA, unclamped_t=False):
+    """-> d(sum grad_sil*sil)/d(v_ndc[:, :2])  (V,2) float64.  unclamped_t: the adjoint with the edge parameter left unclamped
+    (smal_oracle.EDGE_T_UNCLAMPED, SMALFIT_OPT_UNCLAMPED_EDGE_T) instead of the exact gradient"""
     lib = _load()
     v = np.ascontiguousarray(v_ndc, np.float32)
     f = np.ascontiguousarray(faces, np.int32)
@@ -54,5 +55,5 @@ def backward(v_ndc, faces, S, p2f, dists, grad_sil, K=100, sigma=SIGMA):
     lib.raster_naive_backward(v.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p), C.c_int(S), C.c_int(K),
                               C.c_float(sigma), np.ascontiguousarray(p2f, np.int32).ctypes.data_as(C.c_void_p),
                               np.ascontiguousarray(dists, np.float32).ctypes.data_as(C.c_void_p),
-                              g.ctypes.data_as(C.c_void_p), gv.ctypes.data_as(C.c_void_p))
+                              g.ctypes.data_as(C.c_void_p), gv.ctypes.data_as(C.c_void_p), C.c_int(1 if unclamped_t else 0))
     return gv

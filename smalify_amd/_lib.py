@@ -11,7 +11,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 4                    # SMALFIT_ABI_VERSION of include/smalfit.h this binding mirrors
+ABI_VERSION = 5                    # SMALFIT_ABI_VERSION of include/smalfit.h this binding mirrors
 LIB_PATH = os.environ.get("SMALFIT_LIB") or os.path.join(_HERE, "libsmalfit.so")   # override: development builds
 CSRC = os.path.join(_HERE, "csrc")
 
@@ -112,6 +112,7 @@ SIGNATURES = {
     "smalfit_engine_set_shape_prior": (_I, [_VP, _VP, _VP, _I]),
     "smalfit_engine_set_joint_limits": (_I, [_VP, _VP, _VP]),
     "smalfit_engine_clear_joint_limits": (_I, [_VP]),
+    "smalfit_engine_set_option": (_I, [_VP, _I, _I]),
     "smalfit_lbs_forward": (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "smalfit_lbs_backward": (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "smalfit_lbs_forward_ex": (_I, [_VP, _VP, C.POINTER(LbsArgs)]),

@@ -116,6 +116,13 @@ class Engine:
         """replay one captured iteration per fit_run step (HIP graph) instead of enqueueing its launches one by one"""
         check(self.lib.smalfit_engine_set_graph(self.handle, int(bool(enable))), "smalfit_engine_set_graph")
 
+    OPT_UNCLAMPED_EDGE_T = 1      # SMALFIT_OPT_UNCLAMPED_EDGE_T of include/smalfit.h
+
+    def set_option(self, option, value):
+        """engine options (include/smalfit.h): OPT_UNCLAMPED_EDGE_T = 1 selects the silhouette adjoint with the edge parameter left
+        unclamped (what some pytorch3d 0.2.x sources are recalled to do); the default 0 is the exact gradient"""
+        check(self.lib.smalfit_engine_set_option(self.handle, int(option), int(value)), "smalfit_engine_set_option")
+
     def clear_joint_limits(self):
         """back to the reference's behaviour: the w_limit column is ignored (its term is commented out upstream)"""
         check(self.lib.smalfit_engine_clear_joint_limits(self.handle), "smalfit_engine_clear_joint_limits")

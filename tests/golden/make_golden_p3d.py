@@ -17,6 +17,11 @@ from the reference's constants (camera look_at_view_transform(2.7, 0, 0) + OpenG
     head-on view (the reference's initial pose), 32 x 32: every covered pixel has far more than 100 candidate faces -- the
         K = 100 nearest-in-depth truncation, its tie handling and the pz >= 0 / kEpsilon culls are what this case pins
 
+    vertex-nearest anchor (tests/raster_anchors.py::vertex_nearest_gradient): one triangle, one pixel whose nearest feature is a
+        VERTEX -- d sil / d verts there tells whether this pytorch3d clamps the edge parameter t in PointLineDistanceBackward
+        (last row).  The two conventions are different closed forms; tests/test_p3d_fixture.py reports which one the
+        fixture follows, i.e. whether smalfit_engine_set_option(SMALFIT_OPT_UNCLAMPED_EDGE_T, 1) is the setting that reproduces it.
+
 tests/test_p3d_fixture.py consumes the file when it exists (oracle on the CPU, HIP kernels on the GPU) and is reported as
 skipped otherwise.  Without pytorch3d this script exits with a message and writes nothing.
 """
@@ -100,6 +105,15 @@ def main():
                     tag + "_image_size": np.array(S)})
         out["produced_with"] = np.array(how)
         print(tag, "coverage %.3f" % float((sil > 0.5).float().mean()), how)
+    # the vertex-nearest anchor: d sil[row, col] / d verts of ONE triangle (answers SURVEY App. B's open question for this pytorch3d)
+    from tests import raster_anchors as ra
+    av, af, aS, (arow, acol), _ = ra.vertex_nearest_gradient()
+    renderer, how = build_renderer(aS, torch)
+    averts = torch.from_numpy(av[None].astype(np.float32)).requires_grad_(True)
+    ares = renderer(averts, torch.zeros(1, 1, 3), torch.from_numpy(af.astype(np.int64))[None])
+    ares[0][0, 0, arow, acol].backward()
+    out.update({"anchor_vertex_sil": ares[0].detach().numpy()[0, 0, arow, acol], "anchor_vertex_dverts": averts.grad.numpy()[0]})
+    print("vertex-nearest anchor: sil %.6f, d sil / d verts" % float(out["anchor_vertex_sil"]), out["anchor_vertex_dverts"].tolist())
     out["faces"] = np.asarray(md.faces).astype(np.int32)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT)

@@ -25,6 +25,10 @@ cur["global_rotation"] += (0.05 * rs.randn(M, 3)).astype(np.float32)
 cur["joint_rotations"] += (0.08 * rs.randn(M, 34, 3)).astype(np.float32)
 cur["trans"] += (0.02 * rs.randn(M, 3)).astype(np.float32)
 cur["betas"] += (0.1 * rs.randn(20)).astype(np.float32)
+# optional second argument: a DRAW index d >= 1 -- the float32 loop starts from an initial translation moved by one unit in the last
+# place (frame 0; axis d % 3, direction by d // 3), the float64 loop from the unperturbed one: float32 arithmetic's own spread on this
+# problem (a 195-step Adam trajectory is one sample of a chaotic map, like tests/config2_case.py's f32b...e draws)
+DRAW = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 om64 = so.OracleModel(md)
 with torch.no_grad():
     theta = np.concatenate([gt["global_rotation"][:, None], gt["joint_rotations"]], 1)
@@ -41,6 +45,11 @@ for name, dt in (("f64", torch.float64), ("f32", torch.float32)):
     om = so.OracleModel(md, dtype=dt)
     prob = so.FitProblem(om, S, tj, vis, tsil, pp[0], pp[1], pp[2], sp[0], sp[1], window, True, dtype=dt)
     params = {k: torch.from_numpy(v).to(dt) for k, v in cur.items()}
+    if DRAW and dt == torch.float32:
+        t0 = params["trans"].numpy().copy()
+        ax = DRAW % 3
+        t0[0, ax] = np.nextafter(t0[0, ax], np.float32(np.inf if (DRAW // 3) % 2 == 0 else -np.inf))
+        params["trans"] = torch.from_numpy(t0)
     for stage, w in enumerate(W):
         names = so.trainable_names(stage)
         v0 = so.stage0_visibility(prob.vis) if stage == 0 else None
@@ -66,6 +75,6 @@ print("per-term |f32 - f64|:", drift["terms_abs_dev"])
 import json, os
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_full_schedule_f32_drift.json")
 doc = json.load(open(out)) if os.path.exists(out) else {"config": dict(M=M, S=S, window=window, seed=seed, iters_scale=0.1, schedule=sched), "draws": []}
-doc["draws"].append(dict({"source": "tests/oracle_float32_drift.py, %d threads" % torch.get_num_threads()}, **drift))
+doc["draws"].append(dict({"source": "tests/oracle_float32_drift.py, %d threads%s" % (torch.get_num_threads(), (", initial trans[0, %d] moved by one ulp (draw %d)" % (DRAW % 3, DRAW)) if DRAW else "")}, **drift))
 json.dump(doc, open(out, "w"), indent=1)
 print("appended a draw to", out)

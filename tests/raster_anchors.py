@@ -185,3 +185,41 @@ def edge_shift_gradient(S=256):
     dsil_dxe = sil * (1.0 - sil) * 2.0 * (x_p - x_e) / SIGMA
     dsil_dworldx_sum = dsil_dxe * (-S_CAM / 2.0)           # z_view = 2.0 for every vertex of the case
     return verts, faces, S, (row, col), dsil_dworldx_sum
+
+
+def vertex_nearest_gradient(S=256):
+    """SURVEY App. B, last row: a pixel whose nearest feature of the triangle is a VERTEX -- the one place where the exact adjoint of
+    the point-segment distance and the one with the edge parameter t left unclamped (some pytorch3d 0.2.x sources,
+    PointLineDistanceBackward) differ.  Triangle a, b, c with the pixel outside beyond a, 1 px above the line through a and b and
+    1.5 px "before" a along it: t = (p - a).(b - a) / |b - a|^2 < 0 is clamped to 0, dist = |p - a|^2 (edges a-b and a-c tie at a;
+    both restatements and the kernels take the first minimum, a-b, like pytorch3d's e01 <= e02 test).  With
+    sil = sigmoid(-dist / sigma), g = d sil / d dist = -sil (1 - sil) / sigma:
+      exact:      d sil / d a = g * 2 (a - p),                    d sil / d b = 0
+      unclamped:  q = (a + t (b - a)) - p (perpendicular foot),   d sil / d a = g (1 - t) 2 q,   d sil / d b = g t 2 q
+    Returns verts (world), faces, S, (row, col), {"exact": (V,2) d sil / d world xy, "unclamped": ...}."""
+    px = 2.0 / S
+    row, col = S // 2, S // 2
+    x_p, y_p = pixel_centre(row, col, S)
+    a = (x_p - 1.5 * px, y_p - 1.0 * px)                 # edge a -> b runs along -x (towards larger columns... NDC +x is left)
+    b = (a[0] - 0.4, a[1])
+    c = (a[0] - 0.2, a[1] - 0.3)
+    tri = [a, b, c]
+    verts = np.stack([world_from_ndc(x, y, 2.0) for x, y in tri])
+    ex, ey = b[0] - a[0], b[1] - a[1]
+    t = ((x_p - a[0]) * ex + (y_p - a[1]) * ey) / (ex * ex + ey * ey)
+    assert t < 0.0
+    dist = (x_p - a[0]) ** 2 + (y_p - a[1]) ** 2
+    assert dist < BLUR and all(w <= 0 for w in barycentric((x_p, y_p), tri)[1:2])    # a candidate, outside
+    assert abs(dist - tri_dist2((x_p, y_p), tri)) < 1e-18
+    sil = sigmoid(-dist / SIGMA)
+    g = -sil * (1.0 - sil) / SIGMA
+    exact = np.zeros((3, 2))
+    exact[0] = [g * 2.0 * (a[0] - x_p), g * 2.0 * (a[1] - y_p)]
+    qx, qy = a[0] + t * ex - x_p, a[1] + t * ey - y_p
+    unclamped = np.zeros((3, 2))
+    unclamped[0] = [g * (1.0 - t) * 2.0 * qx, g * (1.0 - t) * 2.0 * qy]
+    unclamped[1] = [g * t * 2.0 * qx, g * t * 2.0 * qy]
+    # NDC -> world at z_view = 2: x_ndc = -s x / z, y_ndc = s y / z
+    to_world = np.array([-S_CAM / 2.0, S_CAM / 2.0])
+    assert np.abs(exact - unclamped).max() > 0.2 * np.abs(exact).max()     # the case discriminates
+    return verts, np.array([[0, 1, 2]]), S, (row, col), {"exact": exact * to_world, "unclamped": unclamped * to_world, "sil": sil}

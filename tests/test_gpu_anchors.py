@@ -103,6 +103,28 @@ def test_edge_shift_gradient_closed_form():
     assert abs(dv[2, 0]) < 1e-6 * abs(dsum)
 
 
+@pytest.mark.parametrize("unclamped", [False, True])
+def test_vertex_nearest_gradient_both_adjoint_conventions(unclamped):
+    """SURVEY App. B's switch (smalfit_engine_set_option SMALFIT_OPT_UNCLAMPED_EDGE_T): at a pixel whose nearest feature is a vertex the
+    exact adjoint (default) and the unclamped-t one are different closed forms; the kernels reproduce the one the option selects"""
+    verts, faces, S, (row, col), exp = ra.vertex_nearest_gradient()
+    want = exp["unclamped" if unclamped else "exact"]
+    e = _engine(np.asarray(faces), S)
+    e.set_option(e.OPT_UNCLAMPED_EDGE_T, int(unclamped))
+    try:
+        v = _pad(verts)
+        sil, _ = e.render_forward(v)
+        assert abs(float(sil[0, row, col]) - exp["sil"]) < 2e-4
+        dsil = torch.zeros_like(sil)
+        dsil[0, row, col] = 1.0
+        dv = e.render_backward(v, sil, dsil)[0].double().cpu().numpy()
+    finally:
+        e.set_option(e.OPT_UNCLAMPED_EDGE_T, 0)
+    assert np.abs(dv[:3, :2] - want).max() < 3e-3 * np.abs(want).max(), (dv[:3], want)
+    other = exp["exact" if unclamped else "unclamped"]
+    assert np.abs(dv[:3, :2] - other).max() > 0.1 * np.abs(want).max()          # ... and not the other one
+
+
 def test_head_on_gradient_residual_is_float32_depth_ties(capsys):
     """tests/test_gpu_parity.py allows 5e-2 rel-L2 on d(sil)/d(verts) for the head-on view (hundreds of candidates per pixel,
     the K = 100 cut decided by depths that differ in the last float32 bits).  Evidence that this residual is the cut and

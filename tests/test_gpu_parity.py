@@ -129,6 +129,35 @@ def test_global_rigid_transformation_against_reference_golden(golden, scaled):
         batch_global_rigid_transformation(Rs, Js, golden["parents"], rotate_base=True)
 
 
+def test_unclamped_edge_t_option_follows_the_oracle_with_the_same_flag():
+    """SURVEY App. B's switch on a whole mesh: with SMALFIT_OPT_UNCLAMPED_EDGE_T the analytic gradient of a silhouette-stage
+    evaluation equals the oracle's with EDGE_T_UNCLAMPED (custom backward of the point-segment distance), the loss terms do not
+    move, and the two conventions do differ on this problem (so the option is not a no-op)"""
+    from oracle import smal_oracle as so
+    m_exact = pc.case_fit(4, 64, 2, 2)
+    e, _, _, _ = pc.make_problem(4, 64, 2, 21, with_sil=True)
+    e.set_option(e.OPT_UNCLAMPED_EDGE_T, 1)
+    so.EDGE_T_UNCLAMPED = True
+    try:
+        m = pc.case_fit(4, 64, 2, 2)
+        so.EDGE_T_UNCLAMPED = False
+        m_cross = pc.case_fit(4, 64, 2, 2)          # HIP unclamped against the EXACT oracle: must NOT agree
+    finally:
+        so.EDGE_T_UNCLAMPED = False
+        e.set_option(e.OPT_UNCLAMPED_EDGE_T, 0)
+    keys = [k for k in m if k.startswith("fit_grad_") and k.endswith("_rel")]
+    print("\nunclamped-t option, gradient rel-L2 HIP vs oracle: " + ", ".join("%s exact/exact %.1e  unclamped/unclamped %.1e  unclamped/exact %.1e" %
+                                                                            (k[9:-4], m_exact[k], m[k], m_cross[k]) for k in keys))
+    assert m["fit_status"] == 0 and m["fit_total_rel"] < 1e-4
+    # (looser than the exact adjoint's 2e-3: at a face's THIRD vertex the edges a-c and b-c tie only up to rounding -- |p - c|^2 formed
+    # from c - a and from (b - a) + (c - b) -- so which of the two takes the gradient is decided by the last bit, in float32 here, in
+    # float64 in the oracle and in pytorch3d alike; the exact adjoint does not care, the unclamped one does.  The convention is
+    # ill-conditioned there by construction.)
+    for k in keys:
+        assert m[k] < 1e-2, (k, m[k], m_exact[k])
+    assert max(m_cross[k] for k in keys) > 3.0 * max(m[k] for k in keys), (m, m_cross)
+
+
 def test_full_schedule(capsys):
     """All four stages (scaled to 15 / 40 / 60 / 80 iterations) on 4 frames at 64 x 64, HIP loop (one library call per
     stage) vs the oracle loop: the final loss terms agree (SURVEY section 7 check iii) and the end-of-run relative L2

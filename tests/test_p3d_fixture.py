@@ -42,12 +42,43 @@ def test_oracle_renderer_against_pytorch3d(tag):
     g = np.load(FIXTURE, allow_pickle=False)
     S = int(g[tag + "_image_size"])
     verts = torch.from_numpy(g[tag + "_verts"]).double().requires_grad_(True)
-    sil = so.soft_silhouette(verts, torch.from_numpy(g["faces"].astype(np.int64)), S)
-    (sil * torch.from_numpy(g[tag + "_w"]).double()).sum().backward()
+    so.EDGE_T_UNCLAMPED = p3d_backward_convention() == "unclamped"
+    try:
+        sil = so.soft_silhouette(verts, torch.from_numpy(g["faces"].astype(np.int64)), S)
+        (sil * torch.from_numpy(g[tag + "_w"]).double()).sum().backward()
+    finally:
+        so.EDGE_T_UNCLAMPED = False
     assert np.abs(sil.detach().numpy() - g[tag + "_sil"]).max() < 2e-4, tag
     assert _rel(verts.grad.numpy(), g[tag + "_dverts"]) < (5e-2 if tag == "headon32" else 2e-3), tag
     proj = so.project_points(torch.from_numpy(g[tag + "_points"]).double(), S).numpy()
     assert np.abs(proj - g[tag + "_proj"]).max() < 1e-3, tag
+
+
+def p3d_backward_convention():
+    """which adjoint of the point-segment distance the fixture's pytorch3d computes: "exact" (t clamped, the default everywhere
+    here) or "unclamped" (last row) -- read off the vertex-nearest anchor, whose two answers are closed forms
+    (tests/raster_anchors.py::vertex_nearest_gradient).  None when the fixture predates the anchor."""
+    from tests import raster_anchors as ra
+    g = np.load(FIXTURE, allow_pickle=False)
+    if "anchor_vertex_dverts" not in g:
+        return None
+    _, _, _, _, exp = ra.vertex_nearest_gradient()
+    got = np.asarray(g["anchor_vertex_dverts"], np.float64)[:3, :2]
+    err = {k: np.abs(got - exp[k]).max() / np.abs(exp[k]).max() for k in ("exact", "unclamped")}
+    best = min(err, key=err.get)
+    assert err[best] < 5e-3, ("the fixture's anchor gradient matches neither closed form", err, got.tolist())
+    return best
+
+
+@needs_fixture
+def test_which_backward_convention_pytorch3d_follows(capsys):
+    """answers SURVEY App. B's open question from the fixture and says which engine option reproduces it"""
+    conv = p3d_backward_convention()
+    if conv is None:
+        pytest.skip("fixture without the vertex-nearest anchor: regenerate it with tests/golden/make_golden_p3d.py")
+    with capsys.disabled():
+        print("\npytorch3d backward convention by the fixture: %s -> smalfit_engine_set_option(SMALFIT_OPT_UNCLAMPED_EDGE_T, %d)" %
+              (conv, 1 if conv == "unclamped" else 0))
 
 
 @needs_fixture
@@ -62,7 +93,11 @@ def test_hip_rasteriser_against_pytorch3d(tag):
     verts = torch.from_numpy(g[tag + "_verts"]).cuda().contiguous()
     pts = torch.from_numpy(g[tag + "_points"]).cuda().contiguous()
     sil, proj = e.render_forward(verts, pts)
-    dverts = e.render_backward(verts, sil, torch.from_numpy(g[tag + "_w"]).cuda().contiguous())
+    e.set_option(e.OPT_UNCLAMPED_EDGE_T, int(p3d_backward_convention() == "unclamped"))
+    try:
+        dverts = e.render_backward(verts, sil, torch.from_numpy(g[tag + "_w"]).cuda().contiguous())
+    finally:
+        e.set_option(e.OPT_UNCLAMPED_EDGE_T, 0)
     assert e.status() == 0
     assert np.abs(sil.cpu().numpy() - g[tag + "_sil"]).max() < 2e-4, tag
     assert np.abs(proj.cpu().numpy() - g[tag + "_proj"]).max() < 2e-3, tag

@@ -87,3 +87,30 @@ def test_edge_shift_gradient_closed_form():
     got = float(v.grad[0, 0, 0] + v.grad[0, 1, 0])             # the edge's two end points, world x
     assert abs(got - dsum) < 1e-6 * abs(dsum), (got, dsum)
     assert abs(float(v.grad[0, 2, 0])) < 1e-12                 # the far vertex does not move that edge
+
+
+@pytest.mark.parametrize("unclamped", [False, True])
+def test_vertex_nearest_gradient_both_adjoint_conventions(unclamped):
+    """SURVEY App. B's switch: where the nearest feature is a vertex, the exact adjoint and the unclamped-t one differ by known
+    closed forms; both oracle restatements reproduce the one their flag selects (the forward is the same either way)"""
+    verts, faces, S, (row, col), exp = ra.vertex_nearest_gradient()
+    want = exp["unclamped" if unclamped else "exact"]
+    so.EDGE_T_UNCLAMPED = unclamped
+    try:
+        v = torch.from_numpy(verts)[None].requires_grad_(True)
+        sil = so.soft_silhouette(v, torch.from_numpy(faces.astype(np.int64)), S)
+        assert abs(float(sil[0, row, col].detach()) - exp["sil"]) < 1e-9
+        sil[0, row, col].backward()
+    finally:
+        so.EDGE_T_UNCLAMPED = False
+    got = v.grad[0, :, :2].numpy()
+    assert np.abs(got - want).max() < 1e-7 * np.abs(want).max(), (got, want)
+    # the literal float32 restatement (gradient with respect to the NDC positions; z_view = 2 for every vertex)
+    xn, yn, zv = so.world_to_ndc(torch.from_numpy(verts))
+    v_ndc = np.stack([xn.numpy(), yn.numpy(), zv.numpy()], 1).astype(np.float32)
+    sil_n, p2f, _, dists, _ = raster_naive.forward(v_ndc, faces.astype(np.int32), S)
+    gs = np.zeros((S, S), np.float32)
+    gs[row, col] = 1.0
+    gv = raster_naive.backward(v_ndc, faces.astype(np.int32), S, p2f, dists, gs, unclamped_t=unclamped)
+    to_world = np.array([-ra.S_CAM / 2.0, ra.S_CAM / 2.0])
+    assert np.abs(gv * to_world - want).max() < 2e-3 * np.abs(want).max(), (gv * to_world, want)
