@@ -60,9 +60,9 @@ SCHEDULE_ITERS = (150, 400, 600, 800)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 INTERNAL_WARMUP = int(os.environ.get("SMALFIT_BENCH_MIN_WARMUP", "40"))           # minimum number of untimed iterations before the timed region
 PROFILE_STRIDE = 8
-PMC_SUMMARY = os.path.join("profiles", "r5_pmc_summary.json")              # rocprofv3 PMC passes of `bench.py --steps 39` (tools/pmc_sq.py)
-PMC_SUMMARY_CROP = os.path.join("profiles", "r5_pmc_summary_crop.json")    # ... of `tools/crop_fit.py crop 0.3` (the crop-filling scene)
-ISA_MIX = os.path.join("profiles", "r5_isa_mix.json")                      # tools/isa_mix.py: instruction mix x measured issue costs
+PMC_SUMMARY = os.path.join("profiles", "r6_pmc_summary.json")              # rocprofv3 PMC passes of `bench.py --steps 39` (tools/pmc_sq.py)
+PMC_SUMMARY_CROP = os.path.join("profiles", "r6_pmc_summary_crop.json")    # ... of `tools/crop_fit.py crop 0.3` (the crop-filling scene)
+FULL_RATE_CYCLES = 2.0          # cycles a full-rate wave64 vector instruction occupies a SIMD (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2)
 NUM_SIMDS = 1024                # 256 CUs x 4
 PEAK_CLOCK_GHZ = 2.4            # /opt/skills/guides/MI355X_MICROARCH.md: max clock 2400 MHz
 ORACLE_TARGETS = {"survey": os.path.join("tests", "golden", "eval_targets_config3.npz"),
@@ -116,7 +116,24 @@ def build_problem(engine, torch, scene):
         shape = tuple(int(x) for x in z["shape"])
         if shape == (N, S, S):
             tsil = np.unpackbits(z["tsil_bits"])[:N * S * S].reshape(shape).astype(np.float32)
-            TARGET_SOURCE[scene] = "float64 CPU oracle (%s)" % ORACLE_TARGETS[scene]
+            # the committed targets must belong to THIS ground-truth draw (they are data made offline; `gt`, the noise and the visibility
+            # are re-drawn here): one untimed evaluation of the ground truth -- its projected keypoints + the seeded noise must be the
+            # stored keypoints, its silhouette the stored one up to the few rim pixels float32 and float64 decide differently.  Stale
+            # targets fail loudly instead of being fitted.
+            sil = torch.empty(N, S, S, device=dev)
+            proj = torch.empty(N, 25, 2, device=dev)
+            engine.fit_eval(betas=t(gt["betas"]), log_beta_scales=t(gt["log_beta_scales"]), global_rotation=t(gt["global_rotation"]),
+                            joint_rotations=t(gt["joint_rotations"]), trans=t(gt["trans"]), target_joints=None, target_visibility=None,
+                            target_sil=None, weights=(0, 0, 0, 0, 0, 0), w_temp=0.0, window=WINDOW, want=(), sil_out=sil, proj_out=proj)
+            noise, vis = synthetic.keypoint_noise_and_visibility(N)
+            kp_err = float((proj + t(noise) - t(z["tj"])).abs().max())
+            sil_diff = float(((sil > 0.5).float() - t(tsil)).abs().mean())
+            vis_same = bool(np.array_equal(np.asarray(vis, np.float32), np.asarray(z["vis"], np.float32)))
+            if kp_err > 0.05 or sil_diff > 2e-4 or not vis_same:
+                raise RuntimeError("%s does not belong to today's ground-truth draw (keypoints off by %.3g px, %.3g of the silhouette pixels differ, "
+                                   "visibility equal: %s): regenerate it with tests/golden/make_oracle_eval.py targets" % (ORACLE_TARGETS[scene], kp_err, sil_diff, vis_same))
+            TARGET_SOURCE[scene] = "float64 CPU oracle (%s; checked against the ground-truth draw: keypoints within %.1e px, %.1e of the silhouette pixels differ)" % (
+                ORACLE_TARGETS[scene], kp_err, sil_diff)
             return gt, t(z["tj"]), t(z["vis"]), t(tsil), sp
     TARGET_SOURCE[scene] = "the engine's own rasteriser (sil > 0.5)"
     sil = torch.empty(N, S, S, device=dev)
@@ -406,32 +423,30 @@ def main():
         algo_bytes = algo.get(dom_name)
         achieved = algo_bytes / (dom * 1e-3) / 1e9 if dom else None
         def issue_and_traffic(kernel, launch_ms, algo, summary_path):
-            """`roofline.issue`: vector instructions per launch (SQ_INSTS_VALU of the committed PMC summary) x the blended issue cost
-            of that kernel's instruction mix (tools/isa_mix.py over the cost table measured with tools/ubench/valu_rate2.hip), as a
-            fraction of the cycles 1024 SIMDs offer in the measured launch time at the peak clock -- the ceiling that binds these
-            kernels (the HBM fraction of a 3 MB input cannot show progress).  `traffic_ratio`: counter bytes / algorithmic bytes."""
+            """`roofline.issue`: how busy the vector ALUs were -- vector wave-instructions per launch (SQ_INSTS_VALU of the committed PMC
+            summary) x the 2 cycles a full-rate wave64 instruction occupies a SIMD (/opt/skills/guides/MI355X_MICROARCH.md, "Per-instruction
+            cycle constants": v_fma_f32 wave64 = 2 cycles) over the cycles 1024 SIMDs offer in the measured launch time at the 2.4 GHz peak
+            clock.  A fraction by construction (round 5 reported a modelled issue cost per instruction instead, which read 1.1); what the
+            half-rate instructions of the mix, dependency stalls and waits take is the distance to 1, and `wait_share_of_wave_cycles` says how
+            much of it is waiting.  `traffic_ratio`: counter bytes / algorithmic bytes.  Recomputable by hand from the summary file."""
             out_i, traffic_, src = None, None, None
             try:
                 pmc_ = json.load(open(os.path.join(ROOT, summary_path)))
-                mix = json.load(open(os.path.join(ROOT, ISA_MIX)))
-                if pmc_.get("kernel_source_sha") != kernel_source_sha() or mix.get("kernel_source_sha") != kernel_source_sha():
-                    return None, None, summary_path + " / " + ISA_MIX + " are stale (made on other kernel sources): withheld"
+                if pmc_.get("kernel_source_sha") != kernel_source_sha():
+                    return None, None, summary_path + " is stale (made on other kernel sources): withheld"
                 row = pmc_["smalfit::" + kernel]
-                cpi = mix["kernels"]["smalfit::" + kernel]["blended_cycles_per_valu"]
                 traffic_ = 1024.0 * (2.0 * row["FETCH_SIZE"] + row["WRITE_SIZE"])      # KiB; FETCH_SIZE x2: the guide's gfx950 correction
                 cycles = NUM_SIMDS * PEAK_CLOCK_GHZ * 1e9 * launch_ms * 1e-3
                 out_i = {"valu_insts_per_launch": row["SQ_INSTS_VALU"], "salu_insts_per_launch": row.get("SQ_INSTS_SALU"),
-                         "blended_cycles_per_valu": cpi, "simds": NUM_SIMDS, "clock_ghz": PEAK_CLOCK_GHZ, "launch_ms": launch_ms,
-                         "frac": row["SQ_INSTS_VALU"] * cpi / cycles,
+                         "full_rate_cycles_per_valu": FULL_RATE_CYCLES, "simds": NUM_SIMDS, "clock_ghz": PEAK_CLOCK_GHZ, "launch_ms": launch_ms,
+                         "frac": row["SQ_INSTS_VALU"] * FULL_RATE_CYCLES / cycles,
+                         "frac_definition": "valu_utilisation = valu_insts_per_launch x %g cycles / (simds x clock x launch time)" % FULL_RATE_CYCLES,
                          "achieved_cycles_per_valu": cycles / row["SQ_INSTS_VALU"],
-                         "frac_note": "modelled issue cycles (static instruction mix x issue costs measured in isolation) over the cycles available at the nominal "
-                                      "peak clock: an estimate good to ~10 %, so a kernel at its issue ceiling reads 0.9-1.05; `achieved_cycles_per_valu` is the "
-                                      "model-free figure (2.6 = every instruction a full-rate one)",
                          "lds_bank_conflict_per_active": (row["SQ_LDS_BANK_CONFLICT"] / row["SQ_LDS_IDX_ACTIVE"]) if row.get("SQ_LDS_IDX_ACTIVE") else None,
                          "wait_share_of_wave_cycles": (row["SQ_WAIT_ANY"] / row["SQ_WAVE_CYCLES"]) if row.get("SQ_WAVE_CYCLES") else None,
                          "traffic_ratio": traffic_ / algo if algo else None}
-                src = summary_path + " (rocprofv3 --pmc, separate passes per counter group; FETCH_SIZE doubled per MI355X_MICROARCH.md) x " + ISA_MIX + \
-                    "; kernel sources " + pmc_["kernel_source_sha"]
+                src = summary_path + " (rocprofv3 --pmc, separate passes per counter group; FETCH_SIZE doubled per MI355X_MICROARCH.md); kernel sources " + \
+                    pmc_["kernel_source_sha"]
             except Exception as exc:
                 src = "unavailable: %r" % (exc,)
             return out_i, traffic_, src
@@ -457,7 +472,7 @@ def main():
                                            for i in range(len(sched))},
             "per_stage_iterations_per_s_primed": {"stage%d" % i: (sched[i] / primed["stage_seconds"][i] if primed["stage_seconds"][i] > 0 and sched[i] else None)
                                                   for i in range(len(sched))},
-            "roofline": {"bound": "hbm", "bound_note": "HBM is the contract's yardstick; what binds this kernel is vector issue: see `issue`", "kernel": kernel_of.get(dom_name), "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "bound_note": "HBM is the contract's yardstick; this kernel is bound by vector issue and waits: see `issue`", "kernel": kernel_of.get(dom_name), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_source": traffic_source, "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": dom,
                          "issue": issue,

@@ -56,15 +56,18 @@ SHARED_NAMES = ("betas", "log_beta_scales")
 
 
 def _loaded_library(stem):
-    """path of the shared object whose file name starts with `stem` among those ALREADY mapped into this process
-    (/proc/self/maps): dlopen of that exact path returns the loaded instance, so the communicator torch created is only ever
-    handed to the library instance that created it.  Raises OSError when none is mapped."""
+    """path of the shared object `stem`.so[.N...] among those ALREADY mapped into this process (/proc/self/maps): dlopen of that
+    exact path returns the loaded instance, so the communicator torch created is only ever handed to the library instance that
+    created it.  The base name must be `stem` followed by .so and an optional version -- a plugin such as librccl-net.so, which may
+    sit at a lower address than librccl.so itself, does not match.  Raises OSError when none is mapped."""
+    import re
+    want = re.compile(r"^" + re.escape(stem) + r"\.so(\.\d+)*$")
     with open("/proc/self/maps") as maps:
         for line in maps:
             path = line.rsplit(None, 1)[-1]
-            if os.path.basename(path).startswith(stem) and ".so" in path:
+            if want.match(os.path.basename(path)):
                 return path
-    raise OSError("%s is not loaded in this process" % stem)
+    raise OSError("%s.so is not loaded in this process" % stem)
 
 
 class ShardedFitter:
@@ -140,10 +143,12 @@ class ShardedFitter:
 
     def prove_world(self):
         """-> dict for a benchmark line / a test: what the collective the sharded loop uses really spans.  Every rank puts
-        (rank + 1) into the first float of its record and the function pointer handed to smalfit_shard_run gathers it -- the same
-        native ncclAllGather call on the same communicator and stream, or the same host callback -- and the result must be
-        1 .. world in rank order.  With the native path the communicator itself is also asked for its size and this rank's index
-        (ncclCommCount / ncclCommUserRank through the library instance torch loaded)."""
+        (rank + 1) into the first float of a 4-float record and the ranks' records are gathered: with the native path through the very
+        function pointer handed to smalfit_shard_run (the same ncclAllGather call on the same communicator and stream; the communicator
+        is also asked for its size and this rank's index, ncclCommCount / ncclCommUserRank through the library instance torch loaded);
+        with a host transport (gloo, or SMALFIT_SHARD_HOST_COLLECTIVE=1) through torch.distributed's all_gather_into_tensor on the
+        same process group the host callback uses -- the group is what is proved there, not the callback's own buffers.  The result
+        must be 1 .. world in rank order."""
         fn, ctx, keep, kind = self._collective()
         flat = getattr(self.fitter, "flat", None)
         dev = flat.device if flat is not None else torch.device("cpu")

