@@ -11,12 +11,23 @@ namespace smalfit {
 // kinematic tree by depth: joints of one level are independent, so the chain and its adjoint take `nlev` steps
 // (10 for SMAL) instead of 34.  children lists are in DESCENDING joint order: accumulating a parent's adjoint from its
 // children in that order reproduces the summation order of a plain reverse loop over the joints.
+constexpr int kTreeMaxPass = 16, kTreeMaxChildren = 4;
 struct TreeLevels {
   unsigned char nlev;
   unsigned char lvl_off[36];     // level L owns lvl_joint[lvl_off[L] .. lvl_off[L+1])
   unsigned char lvl_joint[35];
   unsigned char child_off[36];   // joint j owns child_idx[child_off[j] .. child_off[j+1])
   unsigned char child_idx[35];
+  // The walks as a flat schedule (round 6): pass k handles up to five joints of one level (a wave = 5 joints x 12 lanes), levels in
+  // ascending order.  With it a lane reads its joint / parent / children of EVERY pass before the walk starts (independent loads, one
+  // latency) instead of chasing level offset -> joint -> parent -> child list through LDS inside every pass.  `fast` = the tree fits
+  // (at most kTreeMaxPass passes, kTreeMaxChildren children per joint: SMAL's needs 12 and 4); deeper / bushier trees take the
+  // table-driven loops as before.
+  unsigned char fast, npass;
+  unsigned char pass_joint[kTreeMaxPass][8];    // [pass][slot 0..4] joint, 255 = idle slot
+  unsigned char pass_parent[kTreeMaxPass][8];
+  unsigned char pass_nchild[kTreeMaxPass][8];
+  unsigned char pass_child[kTreeMaxPass][8][kTreeMaxChildren];   // in the order of child_idx (descending joint index)
 };
 
 // device-resident model constants (pointers into one allocation owned by smalfit_model)

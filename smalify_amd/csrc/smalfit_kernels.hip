@@ -91,6 +91,21 @@ __device__ __forceinline__ int frame_window_size(int n, const WinMap& w) {
   return rem < w.window ? rem : w.window;
 }
 
+// Phase timers of the latency-chain kernels (developer builds: tools/build_variant.sh NAME -DSMALFIT_DEV_PROBES -DSMALFIT_PHASES;
+// tools/lbs_phases.py): thread 0 of a workgroup adds the shader cycles (s_memtime) between two marks to g_phase[kernel][phase] and
+// counts the workgroup in [kernel][15]; [kernel][14] holds the longest workgroup.  Compiled out of the product.
+#ifdef SMALFIT_PHASES
+__device__ unsigned long long g_phase[12][16];
+#define PHASE_MARK(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define PHASE_ADD(k, i, t0, t1) do { if (threadIdx.x == 0) atomicAdd(&g_phase[k][i], (t1) - (t0)); } while (0)
+#define PHASE_END(k, t0, t1) do { if (threadIdx.x == 0) { atomicAdd(&g_phase[k][15], 1ull); atomicMax(&g_phase[k][14], (t1) - (t0)); atomicAdd(&g_phase[k][13], (t1) - (t0)); } } while (0)
+#else
+#define PHASE_MARK(var)
+#define PHASE_ADD(k, i, t0, t1)
+#define PHASE_END(k, t0, t1)
+#endif
+enum { PH_HEAD_POSE = 0, PH_HEAD_SHAPE, PH_SKIN, PH_VERTEX_BWD, PH_MID_PB, PH_MID_DA, PH_CHAIN, PH_CHAIN_RIDER, PH_ASM_BETA, PH_ASM_ELEM, PH_ASM_LAST, PH_ADAM };
+
 #include "kernels_lbs_forward.inc"
 #include "kernels_raster.inc"
 #include "kernels_color.inc"
