@@ -452,7 +452,7 @@ def main():
             return out_i, traffic_, src
 
         ms_per_step = 1e3 * elapsed / args.steps
-        issue, traffic, traffic_source = issue_and_traffic(kernel_of.get(dom_name), dom, algo_bytes, PMC_SUMMARY) if dom_name else (None, None, None)
+        issue, traffic, traffic_source = issue_and_traffic(kernel_of.get(dom_name), dom, algo_bytes, PMC_SUMMARY_CROP if args.scene == "crop" else PMC_SUMMARY) if dom_name else (None, None, None)
         iter_bytes = 2 * 16442644 + NUM_FRAMES * (4 * S * S + 3324)            # 49.88 MB / iteration
         out = {
             "metric": "fitter iterations/sec", "value": args.steps / elapsed, "unit": "iterations/s",
