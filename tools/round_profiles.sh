@@ -18,6 +18,8 @@ PMC_SCRIPT="tools/crop_fit.py crop 0.3" timeout 250 python tools/pmc_sq.py ${tag
 bash tools/prof_cmd.sh ${tag}_crop python tools/crop_fit.py crop 1.0 > $out/${tag}_prof_crop.log 2>&1
 bash tools/prof_cmd.sh ${tag}_8frames python tools/rank_sim.py 8 390 > $out/${tag}_prof_8frames.log 2>&1
 ( cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/trace20; timeout 100 rocprofv3 --kernel-trace --output-format csv -d /tmp/trace20 -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-crop > /dev/null 2>&1; f=$(find /tmp/trace20 -name "*kernel_trace.csv" | head -1); python $GRAFT_REPO_ROOT/tools/trace_window.py $f 20 cold > $GRAFT_REPO_ROOT/$out/${tag}_trace20_cold.txt; python $GRAFT_REPO_ROOT/tools/trace_gaps.py $f 20 > $GRAFT_REPO_ROOT/$out/${tag}_trace20_gaps.txt )
+timeout 300 python -m smalify_amd.tools.work_stats --synthetic --frames 4 --out $out/${tag}_work_stats_standin.txt > /dev/null 2>&1
+if [ -f smalify_amd/_variants/phases.so ]; then SMALFIT_LIB=$PWD/smalify_amd/_variants/phases.so timeout 300 python tools/lbs_phases.py 195 > $out/${tag}_lbs_phase_breakdown.txt 2>&1; fi   # tools/build_variant.sh phases -DSMALFIT_DEV_PROBES -DSMALFIT_PHASES
 # gpurun copies back at most 64 MiB: keep the summaries, drop the raw per-dispatch tables
 rm -rf $out/${tag}_pmc/g[0-9] $out/${tag}_pmc_crop/g[0-9] $out/${tag}_pmc/counters_list.txt $out/${tag}_pmc_crop/counters_list.txt
 for d in $out/prof_${tag}_390 $out/prof_${tag}_crop $out/prof_${tag}_8frames; do
