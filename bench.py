@@ -345,6 +345,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- the collective is proved BEFORE anything is timed (round 6; until then only afterwards): rank stamps through the very
+    # function pointer the sharded loop hands to the library.  The native path (ncclAllGather called from C on torch's communicator)
+    # has never met more than one rank on the builder's boxes: if its proof fails, every rank switches to the host callback
+    # (torch.distributed's own all-gather) -- the verdict is agreed between the ranks -- and the line says so.
+    collective_fallback = None
+    if use_dist:
+        probe = new_fitter()
+        first = probe.prove_world()
+        if not first["ok"] and first.get("collective") == "rccl":
+            collective_fallback = first
+            probe.use_host_collective()
+            again = new_fitter().prove_world()
+            if not again["ok"]:
+                raise SystemExit("bench.py: neither the native nor the host collective spans %d distinct ranks: %r / %r" % (world, first, again))
+        del probe
+
     # ---- warm-up (untimed) --------------------------------------------------------------------------------
     n_warm = max(args.warmup, INTERNAL_WARMUP)
     run(new_fitter(), scaled_schedule(n_warm))
@@ -486,6 +502,8 @@ def main():
         }
         if use_dist:
             out["world_proof"] = world_proof        # rank stamps gathered through the loop's own collective; ncclCommCount / ncclCommUserRank
+            if collective_fallback is not None:
+                out["world_proof"]["native_collective_failed"] = collective_fallback      # the host callback took over (see above)
             out["collective"] = fitter._collective()[3] + ": one all-gather of %d floats per rank and iteration, enqueued by smalfit_shard_run" % (base.num_shared() + 216)
         if crop_cold is not None:
             full = list(SCHEDULE_ITERS)

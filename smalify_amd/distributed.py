@@ -163,8 +163,14 @@ class ShardedFitter:
         else:
             dist.all_gather_into_tensor(recv.view(-1), send, group=self.group)
         stamps = [int(round(float(v))) for v in recv[:, 0].cpu()]
+        ok_here = rc == 0 and stamps == list(range(1, self.world + 1))
+        # every rank must draw the same conclusion (a caller may switch transports on it): the verdict is the AND over the ranks,
+        # taken through torch.distributed itself -- a transport that does not depend on the path under test
+        flag = torch.tensor([1 if ok_here else 0], device=dev, dtype=torch.int32)
+        if self.world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         out = {"collective": kind, "world_size": self.world, "rank_stamps": stamps, "rc": int(rc),
-               "distinct_ranks": len(set(stamps)), "ok": rc == 0 and stamps == list(range(1, self.world + 1))}
+               "distinct_ranks": len(set(stamps)), "ok_this_rank": ok_here, "ok": bool(int(flag.item()))}
         if kind == "rccl":
             try:
                 rccl = ctypes.CDLL(_loaded_library("librccl"))
@@ -177,6 +183,13 @@ class ShardedFitter:
             except (OSError, AttributeError) as exc:
                 out["ncclCommCount_error"] = str(exc)
         return out
+
+    def use_host_collective(self):
+        """route the sharded loop's all-gather through torch.distributed (a host callback per iteration) instead of the library's own
+        ncclAllGather call from now on -- what SMALFIT_SHARD_HOST_COLLECTIVE=1 selects from the start.  Every rank must call it."""
+        os.environ["SMALFIT_SHARD_HOST_COLLECTIVE"] = "1"
+        self._coll = None
+        self._halo_valid = False
 
     def _buffers(self):
         f = self.fitter
